@@ -1,0 +1,209 @@
+/*
+ * yume_hip.h — C ABI of the MI355X (gfx950) transform-and-visibility path for the Yume engine.
+ *
+ * This is the drop-in boundary: everything the engine-side FFI module (`engine/hip/hip.zig`,
+ * `extern fn` declarations, one per symbol below) binds.  Plain C: opaque handles, plain pointers
+ * and sizes, `int` status codes, no exceptions, no C++/torch types.
+ *
+ * What each entry point replaces in the reference (paths under the reference tree):
+ *   - the per-frame system  engine/systems/TransformSyncSystem.zig:53-74  (rule A3)
+ *     + engine/systems/PostTransformSystem.zig:27-37 (dirty reset, A7)         -> yh_frame
+ *   - Mat4.compose / fromQuat  engine/math3d.zig:816-822, 727-749 (A5)          -> yh_frame (fused), yh_compose
+ *   - Mat4.mul  engine/math3d.zig:583-610 (A4), Mat4.inverse :763-814 (A8)      -> inside yh_frame
+ *   - column access  engine/ecs.zig:695-705 (`ecs.field`, A9) and the 68-byte
+ *     {Mat4, bool dirty} component layout engine/components/transform.zig:8-12,62-66 (A1)
+ *                                                   -> yh_upload_*_aos68 / yh_download_*_aos68
+ *   - hierarchy source of truth (ChildOf pairs) engine/ecs.zig:328-343,470-477 (A10)
+ *                                                   -> yh_upload_hierarchy
+ *   - culling has no counterpart in the reference: the OBB-vs-6-plane test is
+ *     defined by this build; bounds come from engine/meshes.zig:72-95 (BoundingBox{mins,maxs}),
+ *     frusta from engine/components/camera.zig:253-302 (view_projection).
+ *
+ * Conventions: Mat4 is 16 x f32 column-major, values[c*4+r] (engine/math3d.zig:529-549).
+ * All arithmetic is IEEE f32, unfused, left-to-right, exactly as the reference evaluates it.
+ *
+ * Ownership: the library owns all device memory and streams.  Host pointers are borrowed for
+ * the duration of the call only.  Threading: one host thread per yh_ctx at a time.
+ * Errors: 0 = ok, negative yh_status otherwise; yh_last_error() gives a message.  Nothing
+ * aborts or throws across this boundary.
+ */
+#ifndef YUME_HIP_H
+#define YUME_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YH_ABI_VERSION 1u
+#define YH_MAX_FRUSTA 8u   /* frusta per frame (main camera + shadow cascades) */
+#define YH_MAX_LEVELS 64u  /* hierarchy depth limit */
+#define YH_NO_PARENT 0xFFFFFFFFu
+
+typedef enum yh_status {
+    YH_OK = 0,
+    YH_ERR_BAD_ARG = -1,   /* null pointer, range out of bounds, malformed hierarchy */
+    YH_ERR_OOM = -2,       /* host or device allocation failed */
+    YH_ERR_HIP = -3,       /* a HIP runtime call failed */
+    YH_ERR_RCCL = -4,      /* RCCL missing or a collective failed */
+    YH_ERR_CAPACITY = -5,  /* a draw list or caller buffer is too small (required size reported) */
+    YH_ERR_STATE = -6,     /* call order violated (e.g. frame before hierarchy upload) */
+    YH_ERR_UNSUPPORTED = -7
+} yh_status;
+
+typedef struct yh_ctx yh_ctx;     /* one GPU: device, stream, events, optional RCCL communicator */
+typedef struct yh_scene yh_scene; /* device-resident entity arrays of one (shard of a) scene   */
+
+/* How local transforms are held on the device. */
+typedef enum yh_local_kind {
+    YH_LOCAL_TRS = 0, /* 10 f32 SoA planes tx,ty,tz,qx,qy,qz,qw,sx,sy,sz; stage 1 = batched Mat4.compose */
+    YH_LOCAL_MAT4 = 1 /* 16 f32 SoA planes (imported flecs LocalTransform column); carries dirty flags     */
+} yh_local_kind;
+
+/* Where local-space bounds come from. */
+typedef enum yh_bounds_kind {
+    YH_BOUNDS_NONE = 0,       /* no culling inputs: transforms only                               */
+    YH_BOUNDS_PER_ENTITY = 1, /* 6 f32 SoA planes min.xyz, max.xyz                                */
+    YH_BOUNDS_MESH_TABLE = 2  /* u32 mesh id per entity + table of n_meshes x {min.xyz, max.xyz}  */
+} yh_bounds_kind;
+
+typedef struct yh_scene_desc {
+    uint64_t n_entities;      /* <= 2^32 - 2 */
+    uint32_t n_levels;        /* hierarchy depth, 1 = flat; <= YH_MAX_LEVELS */
+    uint32_t n_frusta;        /* draw lists kept per frame; <= YH_MAX_FRUSTA */
+    uint32_t local_kind;      /* yh_local_kind  */
+    uint32_t bounds_kind;     /* yh_bounds_kind */
+    uint32_t max_meshes;      /* YH_BOUNDS_MESH_TABLE only */
+    uint32_t id_base;         /* added to every emitted draw index (shard_base of this GPU) */
+    uint64_t draw_capacity;   /* entries per draw list; 0 = n_entities */
+} yh_scene_desc;
+
+/* yh_frame flags */
+#define YH_FRAME_ALL_DIRTY   0x1u /* every LocalTransform is dirty: forward branch everywhere (benchmark mode;
+                                     the only mode of YH_LOCAL_TRS scenes)                                   */
+#define YH_FRAME_NO_CULL     0x2u /* skip stage 3 */
+#define YH_FRAME_ASYNC       0x4u /* enqueue only; yh_wait() or any yh_get_ / yh_download_ call synchronises */
+#define YH_FRAME_ORDERED     0x8u /* draw lists in ascending entity order (two-pass scan instead of atomics) */
+
+typedef struct yh_timing {
+    float last_frame_ms;    /* device time of the most recent completed frame (hipEvent)            */
+    float last_kernel_ms;   /* device time of its longest kernel launch                             */
+    uint32_t n_launches;    /* kernel launches in that frame                                        */
+    uint32_t n_groups;      /* level groups the hierarchy was cut into                              */
+    uint64_t frames;        /* frames run on this scene                                             */
+} yh_timing;
+
+typedef struct yh_device_info {
+    int device_id;
+    int n_cus;
+    int wavefront_size;
+    uint64_t hbm_bytes;
+    char arch[32];  /* "gfx950" */
+    char name[128];
+} yh_device_info;
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+uint32_t yh_abi_version(void);
+int yh_init(int device_id, yh_ctx** out);                 /* GameApp.zig:50-66 analogue: once at start-up */
+void yh_shutdown(yh_ctx* ctx);
+const char* yh_last_error(const yh_ctx* ctx);             /* ctx may be NULL: last error of this thread   */
+int yh_device_info_get(yh_ctx* ctx, yh_device_info* out);
+int yh_wait(yh_ctx* ctx);                                 /* drain the context's stream                    */
+void* yh_stream(yh_ctx* ctx);                             /* the hipStream_t all work is enqueued on       */
+
+/* ---- scene --------------------------------------------------------------------------------------------- */
+int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* desc, yh_scene** out);
+void yh_scene_destroy(yh_scene* scene);
+
+/* Depth-sorted hierarchy (A10): entities are stored level-major, siblings contiguous and sorted by parent.
+ * parent_index[e] is the slot of e's parent (an entity of the previous level) or YH_NO_PARENT for level 0,
+ * whose parent is the scene root (GameApp.zig:77,95).  level_offsets has n_levels+1 entries.           */
+int yh_upload_hierarchy(yh_scene* s, const uint32_t* parent_index, const uint32_t* level_offsets);
+/* WorldTransform of the scene root (GameApp.zig:95); identity until set. */
+int yh_set_root(yh_scene* s, const float root_world[16]);
+
+/* Stage-1 inputs: SoA TRS planes, order tx,ty,tz,qx,qy,qz,qw,sx,sy,sz (Mat4.compose arguments,
+ * math3d.zig:816).  Entities [first, first+count).                                                       */
+int yh_upload_trs(yh_scene* s, const float* const planes[10], uint64_t first, uint64_t count);
+/* flecs table columns, 68-byte rows {float m[16]; uint8 dirty; pad[3]} (transform.zig:8-12, 62-66),
+ * as returned by ecs.field (ecs.zig:695-705).  Scene must be YH_LOCAL_MAT4.                             */
+int yh_upload_local_aos68(yh_scene* s, const void* column, uint64_t first, uint64_t count);
+int yh_upload_world_aos68(yh_scene* s, const void* column, uint64_t first, uint64_t count);
+/* The onSet hooks (transform.zig:46-51, 92-97): mark a range dirty without re-uploading matrices.       */
+int yh_mark_dirty(yh_scene* s, int local, int world, uint64_t first, uint64_t count);
+
+/* Bounds (meshes.zig:72-95). */
+int yh_upload_aabb(yh_scene* s, const float* const min_planes[3], const float* const max_planes[3],
+                   uint64_t first, uint64_t count);
+int yh_upload_mesh_aabbs(yh_scene* s, const float* table /* n_meshes x 6: min.xyz,max.xyz */, uint32_t n_meshes);
+int yh_upload_mesh_ids(yh_scene* s, const uint32_t* mesh_id, uint64_t first, uint64_t count);
+
+/* ---- per frame ----------------------------------------------------------------------------------------- */
+/* One pass of the hot path over the whole scene: compose -> level-ordered propagate -> cull + compact,
+ * then dirty reset.  planes: n_frusta x 6 x 4 floats (nx,ny,nz,d), normalised, order L,R,B,T,N,F
+ * (yh_extract_planes).  Replaces one `world.progress` worth of TransformSyncSystem + PostTransformSystem
+ * callbacks (Editor.zig:301-306).                                                                        */
+int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uint32_t flags);
+
+/* Results.  counts/boundary: n_frusta entries.  A "boundary" entity has |s + r| < 1e-5 for some plane. */
+int yh_get_counts(yh_scene* s, uint32_t* counts, uint32_t* boundary_counts);
+/* Copies draw list `frustum` to `out`; *written = entries of the list.  If cap is too small returns
+ * YH_ERR_CAPACITY with *written = required size.                                                         */
+int yh_get_draw_list(yh_scene* s, uint32_t frustum, uint32_t* out, uint64_t cap, uint64_t* written);
+/* World matrices: 16 SoA planes (plane p = values[p]) or flecs 68-byte rows (dirty bytes included).     */
+int yh_download_world_soa(yh_scene* s, float* const planes[16], uint64_t first, uint64_t count);
+int yh_download_world_aos68(yh_scene* s, void* column, uint64_t first, uint64_t count);
+int yh_download_local_aos68(yh_scene* s, void* column, uint64_t first, uint64_t count);
+/* Stage 1 alone: Mat4.compose over a range, result as 16 SoA planes on the host (testing aid).          */
+int yh_compose(yh_scene* s, float* const planes[16], uint64_t first, uint64_t count);
+
+int yh_timings(yh_scene* s, yh_timing* out);
+/* Measurement harness (no reference counterpart): HIP events around every launch of yh_frame, on the
+ * context's stream.  yh_scene_get_groups writes up to cap (first_level, last_level, first_entity,
+ * end_entity) quadruples, one per launch; yh_scene_get_group_timings the mean device time per launch
+ * since the previous call (at most 2048 launches are recorded between calls).                           */
+int yh_scene_set_kernel_timing(yh_scene* s, int enable);
+int yh_scene_get_groups(yh_scene* s, uint32_t* quads, uint32_t cap, uint32_t* n_groups);
+int yh_scene_get_group_timings(yh_scene* s, float* mean_ms, uint32_t* samples, uint32_t cap);
+/* Hierarchy launches: levels are cut into groups of consecutive levels, one kernel launch per group;
+ * inside a group an entity re-derives its ancestors' matrices instead of waiting for them.
+ * max_group_levels = 1 is one launch per level; 0 = automatic.                                           */
+int yh_scene_set_grouping(yh_scene* s, uint32_t max_group_levels);
+
+/* ---- frustum helpers (host, scalar; same arithmetic as the kernels' inputs expect) --------------------- */
+/* Gribb-Hartmann planes from a column-major view-projection matrix (camera.zig:300-302; depth 0..1 as
+ * math3d.zig:649-659).  Writes 6 x 4 floats, normalised.                                                 */
+void yh_extract_planes(const float view_projection[16], float planes_out[24]);
+void yh_mat4_mul(const float a[16], const float b[16], float out[16]);             /* math3d.zig:583-610 */
+void yh_perspective(float fovy_rad, float aspect, float near_z, float far_z, float out[16]); /* :649-659 */
+void yh_orthographic(float l, float r, float b, float t, float n, float f, float out[16]);   /* :661-683 */
+void yh_look_at(const float eye[3], const float at[3], const float up[3], float out[16]);    /* :991-1021 */
+
+/* ---- synthetic scenes (measurement harness) ---------------------------------------------- */
+typedef struct yh_synth_desc {
+    uint64_t seed;         /* 0x59554D45 in the benchmarks */
+    uint64_t index_base;   /* global index of local entity 0 (so shards of one scene stay consistent) */
+} yh_synth_desc;
+/* Fills TRS (and bounds) planes of the scene on the device from the counter-based generator; the
+ * hierarchy must have been uploaded (level 0 and deeper levels draw from different ranges).              */
+int yh_scene_fill_synthetic(yh_scene* s, const yh_synth_desc* desc);
+int yh_download_trs(yh_scene* s, float* const planes[10], uint64_t first, uint64_t count);
+int yh_download_aabb(yh_scene* s, float* const min_planes[3], float* const max_planes[3], uint64_t first,
+                     uint64_t count);
+
+/* ---- multi-GPU (one process per GPU; RCCL over xGMI) --------------------------------------------------- */
+#define YH_UNIQUE_ID_BYTES 128
+int yh_comm_unique_id(void* out_id /* YH_UNIQUE_ID_BYTES */);
+int yh_comm_init(yh_ctx* ctx, int n_ranks, int rank, const void* unique_id);
+void yh_comm_destroy(yh_ctx* ctx);
+/* All-gather of per-rank visible counts, then of the compacted draw lists (exact sizes, written at
+ * prefix-sum offsets into a library-owned gathered list per frustum).  all_counts: n_ranks x n_frusta.   */
+int yh_allgather_draw_lists(yh_scene* s, uint32_t* all_counts /* may be NULL */);
+int yh_get_gathered_draw_list(yh_scene* s, uint32_t frustum, uint32_t* out, uint64_t cap, uint64_t* written);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YUME_HIP_H */

@@ -1,0 +1,110 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol include/yume_hip.h
+declares, and its scalar host helpers agree with the oracle.  No compute call is made without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "yume_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(yh_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ["yh_init", "yh_shutdown", "yh_scene_create", "yh_upload_trs", "yh_upload_local_aos68",
+                 "yh_upload_hierarchy", "yh_upload_aabb", "yh_frame", "yh_get_counts", "yh_get_draw_list",
+                 "yh_download_world_aos68", "yh_last_error", "yh_timings", "yh_comm_init", "yh_allgather_draw_lists"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from yume_amd import _lib
+
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in include/yume_hip.h but not exported"
+
+
+def test_binding_table_matches_header():
+    from yume_amd import _lib
+
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+    _lib.lib()  # sets argtypes for all of them
+    assert _lib.lib().yh_abi_version() == 1
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    import subprocess
+
+    src = tmp_path / "t.c"
+    src.write_text('#include "yume_hip.h"\nint main(void){ yh_scene_desc d; (void)d; return sizeof(yh_timing) == 24 ? 0 : 1; }\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe)])
+    subprocess.check_call([str(exe)])
+
+
+def test_struct_layouts_match_ctypes():
+    from yume_amd import _lib
+
+    assert C.sizeof(_lib.SceneDesc) == 40
+    assert C.sizeof(_lib.Timing) == 24
+    assert C.sizeof(_lib.SynthDesc) == 16
+    assert C.sizeof(_lib.DeviceInfo) == 4 * 4 + 8 + 32 + 128
+
+
+def test_host_helpers_match_oracle(oracle):
+    from yume_amd import api, synth
+
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        a = rng.standard_normal(16).astype(np.float32)
+        b = rng.standard_normal(16).astype(np.float32)
+        assert np.array_equal(api.mat4_mul(a, b).view(np.uint32), oracle.mul(a, b).view(np.uint32))
+        eye, at = rng.uniform(-50, 50, 3), rng.uniform(-5, 5, 3)
+        assert np.array_equal(api.look_at(eye, at, [0, 1, 0]), oracle.look_at(eye, at, [0, 1, 0]))
+        vp = api.mat4_mul(api.perspective(1.0, 1.5, 0.1, 300.0), api.look_at(eye, at, [0, 1, 0]))
+        assert np.array_equal(api.extract_planes(vp), oracle.extract_planes(vp))
+    assert np.array_equal(api.perspective(1.3, 2.0, 0.1, 200.0), oracle.perspective(1.3, 2.0, 0.1, 200.0))
+    assert np.array_equal(api.orthographic(-10, 10, -10, 10, 0, 200), oracle.orthographic(-10, 10, -10, 10, 0, 200))
+    assert np.array_equal(synth.main_camera_planes(), oracle.main_camera_planes())
+    assert np.array_equal(synth.cascade_planes(), oracle.cascade_planes())
+
+
+def test_harness_hierarchy_matches_oracle(oracle):
+    from yume_amd import synth
+
+    for n, L in [(255, 8), (4096, 8), (100_000, 5), (1_000_000, 8)]:
+        lo = synth.level_offsets(n, L)
+        assert np.array_equal(lo, oracle.synth_level_offsets(n, L))
+        for base in (0, 7 * n):
+            assert np.array_equal(synth.parents(lo, index_base=base), oracle.synth_parents(lo, index_base=base))
+
+
+def test_product_fails_loudly_without_gpu_or_library():
+    """No CPU fallback: without a GPU yh_init reports a HIP error instead of computing anything."""
+    import torch
+
+    from yume_amd import Context, _lib
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.YumeHipError) as e:
+        Context(0)
+    assert e.value.code == _lib.YH_ERR_HIP
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "yume_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".c")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "yume_oracle" not in txt and "import oracle" not in txt, f

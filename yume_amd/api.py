@@ -1,0 +1,296 @@
+"""Thin numpy-facing wrappers over the C ABI (include/yume_hip.h): Context (one GPU) and Scene.
+
+All compute happens in libyume_hip.so's HIP kernels; these classes only marshal pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+T68 = np.dtype({"names": ["m", "dirty", "pad"], "formats": [("<f4", 16), "u1", ("u1", 3)], "itemsize": 68})
+"""flecs column row of LocalTransform / WorldTransform: extern struct { matrix: Mat4, dirty: bool }
+(engine/components/transform.zig:8-12, 62-66): 68 bytes, align 4."""
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _plane_ptrs(arr2d):
+    """(np, n) C-contiguous f32 -> array of np row pointers."""
+    assert arr2d.dtype == np.float32 and arr2d.flags.c_contiguous and arr2d.ndim == 2
+    n = arr2d.shape[0]
+    ptrs = (C.c_void_p * n)()
+    for p in range(n):
+        ptrs[p] = arr2d[p].ctypes.data
+    return ptrs
+
+
+class Context:
+    """One GPU (yh_ctx): device, stream, optional RCCL communicator."""
+
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        L.check(L.lib().yh_init(int(device_id), C.byref(self._h)))
+        self.device_id = device_id
+        self.rank, self.n_ranks = 0, 1
+
+    @property
+    def handle(self):
+        return self._h
+
+    def device_info(self):
+        info = L.DeviceInfo()
+        L.check(L.lib().yh_device_info_get(self._h, C.byref(info)), self._h)
+        return {
+            "device_id": info.device_id,
+            "n_cus": info.n_cus,
+            "wavefront_size": info.wavefront_size,
+            "hbm_bytes": info.hbm_bytes,
+            "arch": info.arch.decode(),
+            "name": info.name.decode(),
+        }
+
+    def wait(self):
+        L.check(L.lib().yh_wait(self._h), self._h)
+
+    def stream(self):
+        return L.lib().yh_stream(self._h)
+
+    # ---- RCCL ----
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_ubyte * L.YH_UNIQUE_ID_BYTES)()
+        L.check(L.lib().yh_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, n_ranks, rank, unique_id):
+        buf = (C.c_ubyte * L.YH_UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        L.check(L.lib().yh_comm_init(self._h, int(n_ranks), int(rank), buf), self._h)
+        self.rank, self.n_ranks = rank, n_ranks
+
+    def close(self):
+        if self._h:
+            L.lib().yh_shutdown(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class Scene:
+    """Device-resident entity arrays of one (shard of a) scene (yh_scene)."""
+
+    def __init__(self, ctx, n_entities, n_levels=1, n_frusta=1, local_kind=L.YH_LOCAL_TRS,
+                 bounds_kind=L.YH_BOUNDS_PER_ENTITY, max_meshes=0, id_base=0, draw_capacity=0):
+        self.ctx = ctx
+        self.n = int(n_entities)
+        self.n_levels = int(n_levels)
+        self.n_frusta = int(n_frusta)
+        self.local_kind = local_kind
+        self.bounds_kind = bounds_kind
+        d = L.SceneDesc(self.n, self.n_levels, self.n_frusta, local_kind, bounds_kind, max_meshes, id_base,
+                        draw_capacity)
+        self._h = C.c_void_p()
+        L.check(L.lib().yh_scene_create(ctx.handle, C.byref(d), C.byref(self._h)), ctx.handle)
+
+    def _ck(self, rc):
+        return L.check(rc, self.ctx.handle)
+
+    def close(self):
+        if self._h:
+            L.lib().yh_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- uploads ----
+    def upload_hierarchy(self, parent_index, level_offsets):
+        p = np.ascontiguousarray(parent_index, np.uint32)
+        lo = np.ascontiguousarray(level_offsets, np.uint32)
+        if p.shape != (self.n,) or lo.shape != (self.n_levels + 1,):
+            raise ValueError("parent_index must have n_entities entries and level_offsets n_levels+1")
+        self._ck(L.lib().yh_upload_hierarchy(self._h, _ptr(p), _ptr(lo)))
+        self.level_offsets = lo.copy()
+
+    def upload_flat(self):
+        """Flat scene: one level, every entity a child of the scene root."""
+        self.upload_hierarchy(np.full(self.n, L.YH_NO_PARENT, np.uint32), np.array([0, self.n], np.uint32))
+
+    def set_root(self, m):
+        m = np.ascontiguousarray(m, np.float32).reshape(16)
+        self._ck(L.lib().yh_set_root(self._h, _ptr(m)))
+
+    def upload_trs(self, trs, first=0):
+        trs = np.ascontiguousarray(trs, np.float32)
+        assert trs.shape[0] == 10
+        self._ck(L.lib().yh_upload_trs(self._h, _plane_ptrs(trs), first, trs.shape[1]))
+
+    def upload_aabb(self, mins, maxs, first=0):
+        mins = np.ascontiguousarray(mins, np.float32)
+        maxs = np.ascontiguousarray(maxs, np.float32)
+        assert mins.shape[0] == 3 and maxs.shape == mins.shape
+        self._ck(L.lib().yh_upload_aabb(self._h, _plane_ptrs(mins), _plane_ptrs(maxs), first, mins.shape[1]))
+
+    def upload_mesh_aabbs(self, table):
+        table = np.ascontiguousarray(table, np.float32).reshape(-1, 6)
+        self._ck(L.lib().yh_upload_mesh_aabbs(self._h, _ptr(table), table.shape[0]))
+
+    def upload_mesh_ids(self, ids, first=0):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        self._ck(L.lib().yh_upload_mesh_ids(self._h, _ptr(ids), first, ids.shape[0]))
+
+    def upload_local_aos68(self, col, first=0):
+        assert col.dtype == T68 and col.flags.c_contiguous
+        self._ck(L.lib().yh_upload_local_aos68(self._h, _ptr(col), first, col.shape[0]))
+
+    def upload_world_aos68(self, col, first=0):
+        assert col.dtype == T68 and col.flags.c_contiguous
+        self._ck(L.lib().yh_upload_world_aos68(self._h, _ptr(col), first, col.shape[0]))
+
+    def mark_dirty(self, local=False, world=False, first=0, count=None):
+        count = self.n - first if count is None else count
+        self._ck(L.lib().yh_mark_dirty(self._h, int(local), int(world), first, count))
+
+    def fill_synthetic(self, seed=0x59554D45, index_base=0):
+        d = L.SynthDesc(seed, index_base)
+        self._ck(L.lib().yh_scene_fill_synthetic(self._h, C.byref(d)))
+
+    def set_grouping(self, max_group_levels):
+        self._ck(L.lib().yh_scene_set_grouping(self._h, int(max_group_levels)))
+
+    # ---- per frame ----
+    def frame(self, planes=None, flags=L.YH_FRAME_ALL_DIRTY):
+        if planes is None:
+            self._ck(L.lib().yh_frame(self._h, None, 0, flags))
+            return
+        planes = np.ascontiguousarray(planes, np.float32).reshape(-1, 24)
+        self._ck(L.lib().yh_frame(self._h, _ptr(planes), planes.shape[0], flags))
+
+    def counts(self):
+        c = np.zeros(L.YH_MAX_FRUSTA, np.uint32)
+        b = np.zeros(L.YH_MAX_FRUSTA, np.uint32)
+        self._ck(L.lib().yh_get_counts(self._h, _ptr(c), _ptr(b)))
+        return c, b
+
+    def draw_list(self, frustum):
+        c, _ = self.counts()
+        out = np.empty(int(c[frustum]), np.uint32)
+        written = C.c_uint64()
+        self._ck(L.lib().yh_get_draw_list(self._h, frustum, _ptr(out), out.shape[0], C.byref(written)))
+        return out[: written.value]
+
+    # ---- downloads ----
+    def world_soa(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.empty((16, count), np.float32)
+        self._ck(L.lib().yh_download_world_soa(self._h, _plane_ptrs(out), first, count))
+        return out
+
+    def world_aos68(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.zeros(count, T68)
+        self._ck(L.lib().yh_download_world_aos68(self._h, _ptr(out), first, count))
+        return out
+
+    def local_aos68(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.zeros(count, T68)
+        self._ck(L.lib().yh_download_local_aos68(self._h, _ptr(out), first, count))
+        return out
+
+    def compose(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.empty((16, count), np.float32)
+        self._ck(L.lib().yh_compose(self._h, _plane_ptrs(out), first, count))
+        return out
+
+    def download_trs(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        out = np.empty((10, count), np.float32)
+        self._ck(L.lib().yh_download_trs(self._h, _plane_ptrs(out), first, count))
+        return out
+
+    def download_aabb(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        mins = np.empty((3, count), np.float32)
+        maxs = np.empty((3, count), np.float32)
+        self._ck(L.lib().yh_download_aabb(self._h, _plane_ptrs(mins), _plane_ptrs(maxs), first, count))
+        return mins, maxs
+
+    # ---- measurement ----
+    def timings(self):
+        t = L.Timing()
+        self._ck(L.lib().yh_timings(self._h, C.byref(t)))
+        return {"last_frame_ms": t.last_frame_ms, "last_kernel_ms": t.last_kernel_ms, "n_launches": t.n_launches,
+                "n_groups": t.n_groups, "frames": t.frames}
+
+    def set_kernel_timing(self, enable):
+        self._ck(L.lib().yh_scene_set_kernel_timing(self._h, int(enable)))
+
+    def groups(self):
+        n = C.c_uint32()
+        q = np.zeros((L.YH_MAX_LEVELS, 4), np.uint32)
+        self._ck(L.lib().yh_scene_get_groups(self._h, _ptr(q), L.YH_MAX_LEVELS, C.byref(n)))
+        return q[: n.value].copy()
+
+    def group_timings(self):
+        ms = np.zeros(L.YH_MAX_LEVELS, np.float32)
+        cnt = np.zeros(L.YH_MAX_LEVELS, np.uint32)
+        self._ck(L.lib().yh_scene_get_group_timings(self._h, _ptr(ms), _ptr(cnt), L.YH_MAX_LEVELS))
+        return ms, cnt
+
+    # ---- multi-GPU ----
+    def allgather_draw_lists(self):
+        out = np.zeros((self.ctx.n_ranks, max(1, self.n_frusta)), np.uint32)
+        self._ck(L.lib().yh_allgather_draw_lists(self._h, _ptr(out)))
+        return out
+
+    def gathered_draw_list(self, frustum, total):
+        out = np.empty(int(total), np.uint32)
+        written = C.c_uint64()
+        self._ck(L.lib().yh_get_gathered_draw_list(self._h, frustum, _ptr(out), out.shape[0], C.byref(written)))
+        return out[: written.value]
+
+
+# ---- frustum helpers (host scalar code in the library; same arithmetic as engine/math3d.zig) ----
+def mat4_mul(a, b):
+    a = np.ascontiguousarray(a, np.float32).reshape(16)
+    b = np.ascontiguousarray(b, np.float32).reshape(16)
+    out = np.empty(16, np.float32)
+    L.lib().yh_mat4_mul(_ptr(a), _ptr(b), _ptr(out))
+    return out
+
+
+def perspective(fovy_rad, aspect, near, far):
+    out = np.empty(16, np.float32)
+    L.lib().yh_perspective(fovy_rad, aspect, near, far, _ptr(out))
+    return out
+
+
+def orthographic(l, r, b, t, n, f):
+    out = np.empty(16, np.float32)
+    L.lib().yh_orthographic(l, r, b, t, n, f, _ptr(out))
+    return out
+
+
+def look_at(eye, at, up):
+    eye, at, up = (np.ascontiguousarray(v, np.float32) for v in (eye, at, up))
+    out = np.empty(16, np.float32)
+    L.lib().yh_look_at(_ptr(eye), _ptr(at), _ptr(up), _ptr(out))
+    return out
+
+
+def extract_planes(view_projection):
+    vp = np.ascontiguousarray(view_projection, np.float32).reshape(16)
+    out = np.empty(24, np.float32)
+    L.lib().yh_extract_planes(_ptr(vp), _ptr(out))
+    return out

@@ -1,0 +1,192 @@
+// yh_math.hpp — register-resident Mat4 math for the gfx950 kernels (and the scalar host helpers).
+//
+// Mirrors the scalar semantics of the reference's engine/math3d.zig: column-major 16 x f32,
+// values[c*4+r]; every expression is evaluated unfused and left to right (the translation unit is
+// built with -ffp-contract=off), so results are the same IEEE values the reference's CPU systems
+// produce.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define YH_HD __host__ __device__ __forceinline__
+
+struct M4 {
+    float v[16];
+};
+
+// engine/math3d.zig:583-610 — full 4x4 product; element (c,r) = A.i[r]*B.c.x + A.j[r]*B.c.y +
+// A.k[r]*B.c.z + A.t[r]*B.c.w, left to right.  Affine structure is deliberately not exploited.
+YH_HD M4 m4_mul(const M4& a, const M4& b) {
+    M4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float bx = b.v[c * 4 + 0], by = b.v[c * 4 + 1], bz = b.v[c * 4 + 2], bw = b.v[c * 4 + 3];
+#pragma unroll
+        for (int row = 0; row < 4; ++row) {
+            r.v[c * 4 + row] = a.v[0 + row] * bx + a.v[4 + row] * by + a.v[8 + row] * bz + a.v[12 + row] * bw;
+        }
+    }
+    return r;
+}
+
+YH_HD M4 m4_identity() {
+    M4 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r.v[i] = 0.0f;
+    r.v[0] = r.v[5] = r.v[10] = r.v[15] = 1.0f;
+    return r;
+}
+
+// engine/math3d.zig:727-749 (fromQuat; quaternion used as given)
+YH_HD M4 m4_from_quat(float x, float y, float z, float w) {
+    const float xx = x * x, yy = y * y, zz = z * z;
+    const float xy = x * y, xz = x * z, yz = y * z;
+    const float wx = w * x, wy = w * y, wz = w * z;
+    M4 r = m4_identity();
+    r.v[0] = 1.0f - 2.0f * (yy + zz);
+    r.v[1] = 2.0f * (xy + wz);
+    r.v[2] = 2.0f * (xz - wy);
+    r.v[4] = 2.0f * (xy - wz);
+    r.v[5] = 1.0f - 2.0f * (xx + zz);
+    r.v[6] = 2.0f * (yz + wx);
+    r.v[8] = 2.0f * (xz + wy);
+    r.v[9] = 2.0f * (yz - wx);
+    r.v[10] = 1.0f - 2.0f * (xx + yy);
+    return r;
+}
+
+// engine/math3d.zig:816-822 evaluated literally: translation.mul(rotation).mul(scale).
+YH_HD M4 m4_compose_literal(float tx, float ty, float tz, float qx, float qy, float qz, float qw, float sx, float sy,
+                            float sz) {
+    M4 t = m4_identity();
+    t.v[12] = tx;
+    t.v[13] = ty;
+    t.v[14] = tz;
+    M4 s = m4_identity();
+    s.v[0] = sx;
+    s.v[5] = sy;
+    s.v[10] = sz;
+    const M4 r = m4_from_quat(qx, qy, qz, qw);
+    return m4_mul(m4_mul(t, r), s);
+}
+
+// Batched Mat4.compose.  The two products of compose only ever add exact zeros to one surviving term
+// per element, so for finite operands the result equals  [R.i*s.x | R.j*s.y | R.k*s.z | (t,1)]  value for
+// value (only the sign of a zero can differ).  A non-finite intermediate anywhere shows up as a
+// non-finite element of that closed form (0*inf = NaN in the literal products), so those lanes take the
+// literal two-product path and produce the reference's NaN pattern exactly.
+YH_HD M4 m4_compose(float tx, float ty, float tz, float qx, float qy, float qz, float qw, float sx, float sy,
+                    float sz) {
+    M4 r = m4_from_quat(qx, qy, qz, qw);
+    r.v[0] = r.v[0] * sx;
+    r.v[1] = r.v[1] * sx;
+    r.v[2] = r.v[2] * sx;
+    r.v[4] = r.v[4] * sy;
+    r.v[5] = r.v[5] * sy;
+    r.v[6] = r.v[6] * sy;
+    r.v[8] = r.v[8] * sz;
+    r.v[9] = r.v[9] * sz;
+    r.v[10] = r.v[10] * sz;
+    r.v[12] = tx;
+    r.v[13] = ty;
+    r.v[14] = tz;
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 15; ++i) {
+        if ((i & 3) != 3) finite = finite && (__builtin_fabsf(r.v[i]) < __builtin_inff());
+    }
+    if (!finite) r = m4_compose_literal(tx, ty, tz, qx, qy, qz, qw, sx, sy, sz);
+    return r;
+}
+
+// engine/math3d.zig:763-814 — cofactor inverse; returns false iff det == 0 exactly.
+YH_HD bool m4_inverse(const M4& m, M4& out) {
+    const float n11 = m.v[0], n21 = m.v[1], n31 = m.v[2], n41 = m.v[3];
+    const float n12 = m.v[4], n22 = m.v[5], n32 = m.v[6], n42 = m.v[7];
+    const float n13 = m.v[8], n23 = m.v[9], n33 = m.v[10], n43 = m.v[11];
+    const float n14 = m.v[12], n24 = m.v[13], n34 = m.v[14], n44 = m.v[15];
+
+    const float t11 = n23 * n34 * n42 - n24 * n33 * n42 + n24 * n32 * n43 - n22 * n34 * n43 - n23 * n32 * n44 + n22 * n33 * n44;
+    const float t12 = n14 * n33 * n42 - n13 * n34 * n42 - n14 * n32 * n43 + n12 * n34 * n43 + n13 * n32 * n44 - n12 * n33 * n44;
+    const float t13 = n13 * n24 * n42 - n14 * n23 * n42 + n14 * n22 * n43 - n12 * n24 * n43 - n13 * n22 * n44 + n12 * n23 * n44;
+    const float t14 = n14 * n23 * n32 - n13 * n24 * n32 - n14 * n22 * n33 + n12 * n24 * n33 + n13 * n22 * n34 - n12 * n23 * n34;
+
+    const float det = n11 * t11 + n21 * t12 + n31 * t13 + n41 * t14;
+    if (det == 0.0f) return false;
+    const float di = 1.0f / det;
+
+    out.v[0] = t11 * di;
+    out.v[1] = (n24 * n33 * n41 - n23 * n34 * n41 - n24 * n31 * n43 + n21 * n34 * n43 + n23 * n31 * n44 - n21 * n33 * n44) * di;
+    out.v[2] = (n22 * n34 * n41 - n24 * n32 * n41 + n24 * n31 * n42 - n21 * n34 * n42 - n22 * n31 * n44 + n21 * n32 * n44) * di;
+    out.v[3] = (n23 * n32 * n41 - n22 * n33 * n41 - n23 * n31 * n42 + n21 * n33 * n42 + n22 * n31 * n43 - n21 * n32 * n43) * di;
+    out.v[4] = t12 * di;
+    out.v[5] = (n13 * n34 * n41 - n14 * n33 * n41 + n14 * n31 * n43 - n11 * n34 * n43 - n13 * n31 * n44 + n11 * n33 * n44) * di;
+    out.v[6] = (n14 * n32 * n41 - n12 * n34 * n41 - n14 * n31 * n42 + n11 * n34 * n42 + n12 * n31 * n44 - n11 * n32 * n44) * di;
+    out.v[7] = (n12 * n33 * n41 - n13 * n32 * n41 + n13 * n31 * n42 - n11 * n33 * n42 - n12 * n31 * n43 + n11 * n32 * n43) * di;
+    out.v[8] = t13 * di;
+    out.v[9] = (n14 * n23 * n41 - n13 * n24 * n41 - n14 * n21 * n43 + n11 * n24 * n43 + n13 * n21 * n44 - n11 * n23 * n44) * di;
+    out.v[10] = (n12 * n24 * n41 - n14 * n22 * n41 + n14 * n21 * n42 - n11 * n24 * n42 - n12 * n21 * n44 + n11 * n22 * n44) * di;
+    out.v[11] = (n13 * n22 * n41 - n12 * n23 * n41 - n13 * n21 * n42 + n11 * n23 * n42 + n12 * n21 * n43 - n11 * n22 * n43) * di;
+    out.v[12] = t14 * di;
+    out.v[13] = (n13 * n24 * n31 - n14 * n23 * n31 + n14 * n21 * n33 - n11 * n24 * n33 - n13 * n21 * n34 + n11 * n23 * n34) * di;
+    out.v[14] = (n14 * n22 * n31 - n12 * n24 * n31 - n14 * n21 * n32 + n11 * n24 * n32 + n12 * n21 * n34 - n11 * n22 * n34) * di;
+    out.v[15] = (n12 * n23 * n31 - n13 * n22 * n31 + n13 * n21 * n32 - n11 * n23 * n32 - n12 * n21 * n33 + n11 * n22 * n33) * di;
+    return true;
+}
+
+// ---- culling (build-defined) -------------------------------------------------------
+// Box centre c = (min+max)*0.5, half extents h = (max-min)*0.5, world centre cw = M*(c,1) in mulVec4 order
+// (engine/math3d.zig:612-620).  Per plane (n,d): s = n.cw + d, r = |n.M.i|*h.x + |n.M.j|*h.y + |n.M.k|*h.z.
+// visible iff s + r >= 0 on all six planes; boundary iff |s + r| < 1e-5 on some plane.
+struct CullBox {
+    float cwx, cwy, cwz, hx, hy, hz;
+};
+
+YH_HD CullBox cull_box(const M4& m, float minx, float miny, float minz, float maxx, float maxy, float maxz) {
+    const float cx = (minx + maxx) * 0.5f, cy = (miny + maxy) * 0.5f, cz = (minz + maxz) * 0.5f;
+    CullBox b;
+    b.hx = (maxx - minx) * 0.5f;
+    b.hy = (maxy - miny) * 0.5f;
+    b.hz = (maxz - minz) * 0.5f;
+    b.cwx = cx * m.v[0] + cy * m.v[4] + cz * m.v[8] + m.v[12];
+    b.cwy = cx * m.v[1] + cy * m.v[5] + cz * m.v[9] + m.v[13];
+    b.cwz = cx * m.v[2] + cy * m.v[6] + cz * m.v[10] + m.v[14];
+    return b;
+}
+
+// planes: 24 floats (6 x nx,ny,nz,d).  Returns bit0 = visible, bit1 = boundary.
+YH_HD uint32_t cull_frustum(const M4& m, const CullBox& b, const float* __restrict__ planes) {
+    bool vis = true, bnd = false;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        const float a = planes[p * 4 + 0], bb = planes[p * 4 + 1], c = planes[p * 4 + 2], d = planes[p * 4 + 3];
+        const float s = a * b.cwx + bb * b.cwy + c * b.cwz + d;
+        const float ri = __builtin_fabsf(a * m.v[0] + bb * m.v[1] + c * m.v[2]);
+        const float rj = __builtin_fabsf(a * m.v[4] + bb * m.v[5] + c * m.v[6]);
+        const float rk = __builtin_fabsf(a * m.v[8] + bb * m.v[9] + c * m.v[10]);
+        const float r = ri * b.hx + rj * b.hy + rk * b.hz;
+        const float t = s + r;
+        vis = vis && (t >= 0.0f);
+        bnd = bnd || (__builtin_fabsf(t) < 1e-5f);
+    }
+    return (vis ? 1u : 0u) | (bnd ? 2u : 0u);
+}
+
+// ---- synthetic scene generator -------------------------------------------------------
+YH_HD uint64_t yh_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+YH_HD uint64_t yh_synth_key(uint64_t seed, uint32_t stream) {
+    return yh_mix64(seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(stream + 1u)));
+}
+YH_HD uint64_t yh_synth_raw(uint64_t seed, uint32_t stream, uint64_t index) {
+    return yh_mix64(yh_synth_key(seed, stream) + index);
+}
+YH_HD float yh_synth_uniform(uint64_t seed, uint32_t stream, uint64_t index, float lo, float hi) {
+    const float u = (float)(uint32_t)(yh_synth_raw(seed, stream, index) >> 40) * 5.9604644775390625e-08f;
+    const float span = hi - lo;
+    return lo + u * span;
+}

@@ -1,0 +1,1041 @@
+// yume_hip.hip — C ABI (include/yume_hip.h) over the gfx950 kernels in yh_kernels.hpp.
+//
+// Host side of the drop-in boundary: owns the device buffers of a scene, cuts the depth-sorted hierarchy
+// into level groups, enqueues one fused kernel per group on the context's stream, and exposes results.
+// One process per GPU; RCCL (dlopen'ed, only when yh_comm_init is called) gathers draw lists across ranks.
+#include "../../include/yume_hip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "yh_kernels.hpp"
+
+static_assert(YH_MAX_FRUSTA == YH_K_MAX_FRUSTA, "header / kernel frustum limits differ");
+
+// ------------------------------------------------------------------------------------------------ state
+struct yh_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+    std::string err;
+    // RCCL (optional)
+    void* rccl_lib = nullptr;
+    void* comm = nullptr;
+    int n_ranks = 1, rank = 0;
+};
+
+struct LevelGroup {
+    uint32_t lo, hi;  // levels [lo, hi]
+};
+
+#define YH_TIMING_RING 2048
+
+struct yh_scene {
+    yh_ctx* ctx = nullptr;
+    yh_scene_desc desc{};
+    uint64_t n = 0, stride = 0, draw_cap = 0;
+    float* trs = nullptr;
+    float* lmat = nullptr;
+    float* world = nullptr;
+    uint32_t* parent = nullptr;
+    float* bounds = nullptr;  // 6 planes, or mesh table
+    uint32_t* mesh_id = nullptr;
+    uint8_t* ldirty = nullptr;
+    uint8_t* wdirty = nullptr;
+    uint32_t* draw[YH_MAX_FRUSTA] = {};
+    uint32_t* counts = nullptr;       // device: 8 visible + 8 boundary
+    uint32_t* h_counts = nullptr;     // pinned mirror
+    void* staging = nullptr;          // device staging for AoS68 import/export
+    uint64_t staging_bytes = 0;
+    std::vector<uint32_t> level_offsets;
+    std::vector<LevelGroup> groups;
+    uint32_t max_group_levels = 0;  // 0 = auto
+    bool have_hierarchy = false;
+    bool frame_pending = false;
+    uint32_t last_n_frusta = 0;
+    uint32_t n_meshes = 0;
+    float root[16];
+    uint32_t root_dirty = 1;  // world.set(scene_root, WorldTransform{IDENTITY}) -> dirty (GameApp.zig:95)
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t frames = 0;
+    uint32_t last_launches = 0;
+    bool kernel_timing = false;
+    std::vector<hipEvent_t> kev;  // YH_TIMING_RING pairs, lazily created
+    std::vector<uint32_t> kev_group;
+    uint32_t kev_used = 0;
+    // gathered lists (multi-GPU)
+    uint32_t* d_all_counts = nullptr;
+    uint32_t* h_all_counts = nullptr;
+    uint32_t* gathered[YH_MAX_FRUSTA] = {};
+    uint64_t gathered_cap[YH_MAX_FRUSTA] = {};
+    uint64_t gathered_len[YH_MAX_FRUSTA] = {};
+};
+
+static thread_local std::string g_err;
+
+static int fail(yh_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                                    \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        if (e_ != hipSuccess)                                                                                 \
+            return fail((ctx), e_ == hipErrorOutOfMemory ? YH_ERR_OOM : YH_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #call, hipGetErrorString(e_), __FILE__, __LINE__);                                    \
+    } while (0)
+
+#define ARG_TRY(ctx, cond, msg)                                   \
+    do {                                                          \
+        if (!(cond)) return fail((ctx), YH_ERR_BAD_ARG, "%s", msg); \
+    } while (0)
+
+static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------- context
+extern "C" uint32_t yh_abi_version(void) { return YH_ABI_VERSION; }
+
+extern "C" const char* yh_last_error(const yh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+extern "C" int yh_init(int device_id, yh_ctx** out) {
+    if (!out) return fail(nullptr, YH_ERR_BAD_ARG, "yh_init: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(nullptr, hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n)
+        return fail(nullptr, YH_ERR_BAD_ARG, "yh_init: device %d out of range (%d devices)", device_id, n);
+    yh_ctx* c = new (std::nothrow) yh_ctx();
+    if (!c) return fail(nullptr, YH_ERR_OOM, "yh_init: out of host memory");
+    c->device = device_id;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&c->prop, device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(nullptr, YH_ERR_HIP, "yh_init: %s", hipGetErrorString(e));
+    }
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string arch = c->prop.gcnArchName;
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(nullptr, YH_ERR_UNSUPPORTED, "yh_init: device is %s; this library is built for gfx950 only",
+                    arch.c_str());
+    }
+    *out = c;
+    return YH_OK;
+}
+
+extern "C" void yh_comm_destroy(yh_ctx* ctx);
+
+extern "C" void yh_shutdown(yh_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    yh_comm_destroy(ctx);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+extern "C" int yh_device_info_get(yh_ctx* ctx, yh_device_info* out) {
+    if (!ctx || !out) return fail(ctx, YH_ERR_BAD_ARG, "yh_device_info_get: NULL argument");
+    memset(out, 0, sizeof *out);
+    out->device_id = ctx->device;
+    out->n_cus = ctx->prop.multiProcessorCount;
+    out->wavefront_size = ctx->prop.warpSize;
+    out->hbm_bytes = ctx->prop.totalGlobalMem;
+    snprintf(out->arch, sizeof out->arch, "%s", ctx->prop.gcnArchName);
+    if (char* colon = strchr(out->arch, ':')) *colon = 0;
+    snprintf(out->name, sizeof out->name, "%s", ctx->prop.name);
+    return YH_OK;
+}
+
+extern "C" int yh_wait(yh_ctx* ctx) {
+    if (!ctx) return fail(nullptr, YH_ERR_BAD_ARG, "yh_wait: ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return YH_OK;
+}
+
+extern "C" void* yh_stream(yh_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// ------------------------------------------------------------------------------------------------ scene
+static void scene_free(yh_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    void* ptrs[] = {s->trs, s->lmat, s->world, s->parent, s->bounds, s->mesh_id, s->ldirty, s->wdirty, s->counts,
+                    s->staging, s->d_all_counts};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (uint32_t f = 0; f < YH_MAX_FRUSTA; ++f) {
+        if (s->draw[f]) (void)hipFree(s->draw[f]);
+        if (s->gathered[f]) (void)hipFree(s->gathered[f]);
+    }
+    if (s->h_counts) (void)hipHostFree(s->h_counts);
+    if (s->h_all_counts) (void)hipHostFree(s->h_all_counts);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    for (hipEvent_t e : s->kev)
+        if (e) (void)hipEventDestroy(e);
+    delete s;
+}
+
+extern "C" void yh_scene_destroy(yh_scene* s) { scene_free(s); }
+
+extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** out) {
+    if (!ctx || !d || !out) return fail(ctx, YH_ERR_BAD_ARG, "yh_scene_create: NULL argument");
+    *out = nullptr;
+    ARG_TRY(ctx, d->n_entities >= 1 && d->n_entities <= 0xFFFFFFFEull, "yh_scene_create: n_entities must be in [1, 2^32-2]");
+    ARG_TRY(ctx, d->n_levels >= 1 && d->n_levels <= YH_MAX_LEVELS, "yh_scene_create: n_levels must be in [1, 64]");
+    ARG_TRY(ctx, d->n_frusta <= YH_MAX_FRUSTA, "yh_scene_create: n_frusta exceeds YH_MAX_FRUSTA");
+    ARG_TRY(ctx, d->local_kind <= YH_LOCAL_MAT4, "yh_scene_create: bad local_kind");
+    ARG_TRY(ctx, d->bounds_kind <= YH_BOUNDS_MESH_TABLE, "yh_scene_create: bad bounds_kind");
+    ARG_TRY(ctx, d->bounds_kind != YH_BOUNDS_MESH_TABLE || d->max_meshes >= 1, "yh_scene_create: max_meshes must be >= 1");
+    ARG_TRY(ctx, d->bounds_kind != YH_BOUNDS_NONE || d->n_frusta == 0, "yh_scene_create: frusta without bounds");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    yh_scene* s = new (std::nothrow) yh_scene();
+    if (!s) return fail(ctx, YH_ERR_OOM, "yh_scene_create: out of host memory");
+    s->ctx = ctx;
+    s->desc = *d;
+    s->n = d->n_entities;
+    s->stride = (s->n + 63) & ~63ull;
+    s->draw_cap = d->draw_capacity ? d->draw_capacity : s->n;
+    for (int i = 0; i < 16; ++i) s->root[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+
+    const uint64_t S = s->stride;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, uint64_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(p, bytes);
+    };
+    if (d->local_kind == YH_LOCAL_TRS) alloc((void**)&s->trs, 10 * S * 4);
+    if (d->local_kind == YH_LOCAL_MAT4) alloc((void**)&s->lmat, 16 * S * 4);
+    alloc((void**)&s->world, 16 * S * 4);
+    alloc((void**)&s->parent, S * 4);
+    alloc((void**)&s->ldirty, S);
+    alloc((void**)&s->wdirty, S);
+    if (d->bounds_kind == YH_BOUNDS_PER_ENTITY) alloc((void**)&s->bounds, 6 * S * 4);
+    if (d->bounds_kind == YH_BOUNDS_MESH_TABLE) {
+        alloc((void**)&s->bounds, (uint64_t)d->max_meshes * 6 * 4);
+        alloc((void**)&s->mesh_id, S * 4);
+    }
+    for (uint32_t f = 0; f < d->n_frusta; ++f) alloc((void**)&s->draw[f], s->draw_cap * 4);
+    alloc((void**)&s->counts, 2 * YH_MAX_FRUSTA * 4);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counts, 2 * YH_MAX_FRUSTA * 4, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+    // world = IDENTITY, dirty: LocalTransform.onAdd (transform.zig:38-44)
+    if (e == hipSuccess) e = hipMemsetAsync(s->world, 0, 16 * S * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->ldirty, 1, S, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->wdirty, 1, S, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->counts, 0, 2 * YH_MAX_FRUSTA * 4, ctx->stream);
+    if (e == hipSuccess) {
+        memset(s->h_counts, 0, 2 * YH_MAX_FRUSTA * 4);
+        const float one = 1.0f;
+        uint32_t bits;
+        memcpy(&bits, &one, 4);
+        for (int p : {0, 5, 10, 15})
+            if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(s->world + (uint64_t)p * S), (int)bits, S, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        int code = fail(ctx, e == hipErrorOutOfMemory ? YH_ERR_OOM : YH_ERR_HIP, "yh_scene_create: %s", hipGetErrorString(e));
+        scene_free(s);
+        return code;
+    }
+    *out = s;
+    return YH_OK;
+}
+
+static int check_range(yh_scene* s, const char* who, uint64_t first, uint64_t count) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "%s: scene is NULL", who);
+    if (first > s->n || count > s->n - first)
+        return fail(s->ctx, YH_ERR_BAD_ARG, "%s: range [%llu, +%llu) exceeds %llu entities", who,
+                    (unsigned long long)first, (unsigned long long)count, (unsigned long long)s->n);
+    return YH_OK;
+}
+
+static int sync_scene(yh_scene* s) {
+    HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    s->frame_pending = false;
+    return YH_OK;
+}
+
+static void plan_groups(yh_scene* s) {
+    s->groups.clear();
+    const uint32_t L = s->desc.n_levels;
+    const uint32_t maxg = s->max_group_levels ? std::min<uint32_t>(s->max_group_levels, YH_MAX_GROUP) : YH_MAX_GROUP;
+    // automatic: a level joins the running group while the group stays small enough that re-deriving
+    // ancestors is cheaper than another dependent launch (~4 us, i.e. ~10^5 entities of streaming).
+    const uint64_t auto_limit = 768 * 1024;
+    uint32_t lo = 0;
+    while (lo < L) {
+        uint32_t hi = lo;
+        while (hi + 1 < L && hi + 1 - lo < maxg) {
+            if (!s->max_group_levels) {
+                const uint64_t merged = (uint64_t)s->level_offsets[hi + 2] - s->level_offsets[lo];
+                if (merged > auto_limit) break;
+            }
+            ++hi;
+        }
+        s->groups.push_back({lo, hi});
+        lo = hi + 1;
+    }
+}
+
+extern "C" int yh_scene_set_grouping(yh_scene* s, uint32_t max_group_levels) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_scene_set_grouping: scene is NULL");
+    ARG_TRY(s->ctx, max_group_levels <= YH_MAX_GROUP, "yh_scene_set_grouping: at most 8 levels per group");
+    s->max_group_levels = max_group_levels;
+    if (s->have_hierarchy) plan_groups(s);
+    return YH_OK;
+}
+
+extern "C" int yh_upload_hierarchy(yh_scene* s, const uint32_t* parent_index, const uint32_t* level_offsets) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_upload_hierarchy: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    ARG_TRY(ctx, parent_index && level_offsets, "yh_upload_hierarchy: NULL argument");
+    const uint32_t L = s->desc.n_levels;
+    ARG_TRY(ctx, level_offsets[0] == 0 && level_offsets[L] == s->n, "yh_upload_hierarchy: level_offsets must span [0, n_entities]");
+    for (uint32_t k = 0; k < L; ++k)
+        ARG_TRY(ctx, level_offsets[k] <= level_offsets[k + 1], "yh_upload_hierarchy: level_offsets must be non-decreasing");
+    // every parent must live in the previous level: this is what makes the kernels' gathers in-bounds
+    for (uint32_t k = 1; k < L; ++k) {
+        const uint32_t plo = level_offsets[k - 1], phi = level_offsets[k];
+        for (uint64_t e = level_offsets[k]; e < level_offsets[k + 1]; ++e) {
+            const uint32_t p = parent_index[e];
+            if (p < plo || p >= phi)
+                return fail(ctx, YH_ERR_BAD_ARG, "yh_upload_hierarchy: entity %llu (level %u) has parent %u outside level %u",
+                            (unsigned long long)e, k, p, k - 1);
+        }
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(s->parent, parent_index, s->n * 4, hipMemcpyHostToDevice));
+    s->level_offsets.assign(level_offsets, level_offsets + L + 1);
+    s->have_hierarchy = true;
+    plan_groups(s);
+    return YH_OK;
+}
+
+extern "C" int yh_set_root(yh_scene* s, const float root_world[16]) {
+    if (!s || !root_world) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_set_root: NULL argument");
+    memcpy(s->root, root_world, sizeof s->root);
+    s->root_dirty = 1;  // WorldTransform.onSet (transform.zig:92-97)
+    return YH_OK;
+}
+
+static int copy_planes_h2d(yh_scene* s, float* dev, const float* const* planes, int np, uint64_t first, uint64_t count) {
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    for (int p = 0; p < np; ++p) {
+        ARG_TRY(s->ctx, planes[p], "plane pointer is NULL");
+        HIP_TRY(s->ctx, hipMemcpy(dev + (uint64_t)p * s->stride + first, planes[p], count * 4, hipMemcpyHostToDevice));
+    }
+    return YH_OK;
+}
+
+static int copy_planes_d2h(yh_scene* s, const float* dev, float* const* planes, int np, uint64_t first, uint64_t count) {
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    if (int rc = sync_scene(s)) return rc;
+    for (int p = 0; p < np; ++p) {
+        ARG_TRY(s->ctx, planes[p], "plane pointer is NULL");
+        HIP_TRY(s->ctx, hipMemcpy(planes[p], dev + (uint64_t)p * s->stride + first, count * 4, hipMemcpyDeviceToHost));
+    }
+    return YH_OK;
+}
+
+extern "C" int yh_upload_trs(yh_scene* s, const float* const planes[10], uint64_t first, uint64_t count) {
+    if (int rc = check_range(s, "yh_upload_trs", first, count)) return rc;
+    ARG_TRY(s->ctx, planes, "yh_upload_trs: planes is NULL");
+    if (s->desc.local_kind != YH_LOCAL_TRS) return fail(s->ctx, YH_ERR_STATE, "yh_upload_trs: scene holds Mat4 locals");
+    return copy_planes_h2d(s, s->trs, planes, 10, first, count);
+}
+
+extern "C" int yh_download_trs(yh_scene* s, float* const planes[10], uint64_t first, uint64_t count) {
+    if (int rc = check_range(s, "yh_download_trs", first, count)) return rc;
+    ARG_TRY(s->ctx, planes, "yh_download_trs: planes is NULL");
+    if (s->desc.local_kind != YH_LOCAL_TRS) return fail(s->ctx, YH_ERR_STATE, "yh_download_trs: scene holds Mat4 locals");
+    return copy_planes_d2h(s, s->trs, planes, 10, first, count);
+}
+
+extern "C" int yh_upload_aabb(yh_scene* s, const float* const min_planes[3], const float* const max_planes[3],
+                              uint64_t first, uint64_t count) {
+    if (int rc = check_range(s, "yh_upload_aabb", first, count)) return rc;
+    ARG_TRY(s->ctx, min_planes && max_planes, "yh_upload_aabb: NULL argument");
+    if (s->desc.bounds_kind != YH_BOUNDS_PER_ENTITY) return fail(s->ctx, YH_ERR_STATE, "yh_upload_aabb: scene has no per-entity bounds");
+    if (int rc = copy_planes_h2d(s, s->bounds, min_planes, 3, first, count)) return rc;
+    return copy_planes_h2d(s, s->bounds + 3 * s->stride, max_planes, 3, first, count);
+}
+
+extern "C" int yh_download_aabb(yh_scene* s, float* const min_planes[3], float* const max_planes[3], uint64_t first,
+                                uint64_t count) {
+    if (int rc = check_range(s, "yh_download_aabb", first, count)) return rc;
+    ARG_TRY(s->ctx, min_planes && max_planes, "yh_download_aabb: NULL argument");
+    if (s->desc.bounds_kind != YH_BOUNDS_PER_ENTITY) return fail(s->ctx, YH_ERR_STATE, "yh_download_aabb: scene has no per-entity bounds");
+    if (int rc = copy_planes_d2h(s, s->bounds, min_planes, 3, first, count)) return rc;
+    return copy_planes_d2h(s, s->bounds + 3 * s->stride, max_planes, 3, first, count);
+}
+
+extern "C" int yh_upload_mesh_aabbs(yh_scene* s, const float* table, uint32_t n_meshes) {
+    if (!s || !table) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_upload_mesh_aabbs: NULL argument");
+    if (s->desc.bounds_kind != YH_BOUNDS_MESH_TABLE) return fail(s->ctx, YH_ERR_STATE, "yh_upload_mesh_aabbs: scene has no mesh table");
+    ARG_TRY(s->ctx, n_meshes >= 1 && n_meshes <= s->desc.max_meshes, "yh_upload_mesh_aabbs: n_meshes out of range");
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    HIP_TRY(s->ctx, hipMemcpy(s->bounds, table, (uint64_t)n_meshes * 24, hipMemcpyHostToDevice));
+    s->n_meshes = n_meshes;
+    return YH_OK;
+}
+
+extern "C" int yh_upload_mesh_ids(yh_scene* s, const uint32_t* mesh_id, uint64_t first, uint64_t count) {
+    if (int rc = check_range(s, "yh_upload_mesh_ids", first, count)) return rc;
+    ARG_TRY(s->ctx, mesh_id, "yh_upload_mesh_ids: mesh_id is NULL");
+    if (s->desc.bounds_kind != YH_BOUNDS_MESH_TABLE) return fail(s->ctx, YH_ERR_STATE, "yh_upload_mesh_ids: scene has no mesh table");
+    ARG_TRY(s->ctx, s->n_meshes >= 1, "yh_upload_mesh_ids: upload the mesh table first");
+    for (uint64_t i = 0; i < count; ++i)
+        if (mesh_id[i] >= s->n_meshes)
+            return fail(s->ctx, YH_ERR_BAD_ARG, "yh_upload_mesh_ids: id %u at %llu >= n_meshes %u", mesh_id[i],
+                        (unsigned long long)(first + i), s->n_meshes);
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    HIP_TRY(s->ctx, hipMemcpy(s->mesh_id + first, mesh_id, count * 4, hipMemcpyHostToDevice));
+    return YH_OK;
+}
+
+static int ensure_staging(yh_scene* s, uint64_t bytes) {
+    if (s->staging_bytes >= bytes) return YH_OK;
+    if (s->staging) HIP_TRY(s->ctx, hipFree(s->staging));
+    s->staging = nullptr;
+    s->staging_bytes = 0;
+    HIP_TRY(s->ctx, hipMalloc(&s->staging, bytes));
+    s->staging_bytes = bytes;
+    return YH_OK;
+}
+
+// rows per staging chunk of the AoS68 import/export (68 MB of staging)
+#define YH_AOS_CHUNK (1u << 20)
+
+static int upload_aos68(yh_scene* s, const void* column, uint64_t first, uint64_t count, float* planes, uint8_t* dirty) {
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    if (int rc = sync_scene(s)) return rc;
+    if (int rc = ensure_staging(s, (uint64_t)std::min<uint64_t>(count ? count : 1, YH_AOS_CHUNK) * 68)) return rc;
+    const char* src = (const char*)column;
+    for (uint64_t done = 0; done < count; done += YH_AOS_CHUNK) {
+        const uint64_t c = std::min<uint64_t>(YH_AOS_CHUNK, count - done);
+        HIP_TRY(s->ctx, hipMemcpyAsync(s->staging, src + done * 68, c * 68, hipMemcpyHostToDevice, s->ctx->stream));
+        hipLaunchKernelGGL(k_aos68_to_soa, dim3(cdiv(c, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream,
+                           (const uint32_t*)s->staging, c, planes, dirty, s->stride, first + done);
+        HIP_TRY(s->ctx, hipGetLastError());
+        HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    }
+    return YH_OK;
+}
+
+static int download_aos68(yh_scene* s, void* column, uint64_t first, uint64_t count, const float* planes, const uint8_t* dirty) {
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    if (int rc = sync_scene(s)) return rc;
+    if (int rc = ensure_staging(s, (uint64_t)std::min<uint64_t>(count ? count : 1, YH_AOS_CHUNK) * 68)) return rc;
+    char* dst = (char*)column;
+    for (uint64_t done = 0; done < count; done += YH_AOS_CHUNK) {
+        const uint64_t c = std::min<uint64_t>(YH_AOS_CHUNK, count - done);
+        hipLaunchKernelGGL(k_soa_to_aos68, dim3(cdiv(c, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream, planes, dirty,
+                           s->stride, first + done, c, (uint32_t*)s->staging);
+        HIP_TRY(s->ctx, hipGetLastError());
+        HIP_TRY(s->ctx, hipMemcpyAsync(dst + done * 68, s->staging, c * 68, hipMemcpyDeviceToHost, s->ctx->stream));
+        HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    }
+    return YH_OK;
+}
+
+extern "C" int yh_upload_local_aos68(yh_scene* s, const void* column, uint64_t first, uint64_t count) {
+    if (int rc = check_range(s, "yh_upload_local_aos68", first, count)) return rc;
+    ARG_TRY(s->ctx, column, "yh_upload_local_aos68: column is NULL");
+    if (s->desc.local_kind != YH_LOCAL_MAT4) return fail(s->ctx, YH_ERR_STATE, "yh_upload_local_aos68: scene holds TRS locals");
+    return upload_aos68(s, column, first, count, s->lmat, s->ldirty);
+}
+
+extern "C" int yh_upload_world_aos68(yh_scene* s, const void* column, uint64_t first, uint64_t count) {
+    if (int rc = check_range(s, "yh_upload_world_aos68", first, count)) return rc;
+    ARG_TRY(s->ctx, column, "yh_upload_world_aos68: column is NULL");
+    return upload_aos68(s, column, first, count, s->world, s->wdirty);
+}
+
+extern "C" int yh_download_world_aos68(yh_scene* s, void* column, uint64_t first, uint64_t count) {
+    if (int rc = check_range(s, "yh_download_world_aos68", first, count)) return rc;
+    ARG_TRY(s->ctx, column, "yh_download_world_aos68: column is NULL");
+    return download_aos68(s, column, first, count, s->world, s->wdirty);
+}
+
+extern "C" int yh_download_local_aos68(yh_scene* s, void* column, uint64_t first, uint64_t count) {
+    if (int rc = check_range(s, "yh_download_local_aos68", first, count)) return rc;
+    ARG_TRY(s->ctx, column, "yh_download_local_aos68: column is NULL");
+    if (s->desc.local_kind != YH_LOCAL_MAT4) return fail(s->ctx, YH_ERR_STATE, "yh_download_local_aos68: scene holds TRS locals");
+    return download_aos68(s, column, first, count, s->lmat, s->ldirty);
+}
+
+extern "C" int yh_download_world_soa(yh_scene* s, float* const planes[16], uint64_t first, uint64_t count) {
+    if (int rc = check_range(s, "yh_download_world_soa", first, count)) return rc;
+    ARG_TRY(s->ctx, planes, "yh_download_world_soa: planes is NULL");
+    return copy_planes_d2h(s, s->world, planes, 16, first, count);
+}
+
+extern "C" int yh_mark_dirty(yh_scene* s, int local, int world, uint64_t first, uint64_t count) {
+    if (int rc = check_range(s, "yh_mark_dirty", first, count)) return rc;
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    if (count == 0) return YH_OK;
+    if (local) hipLaunchKernelGGL(k_fill_u8, dim3(cdiv(count, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream, s->ldirty, (uint8_t)1, first, count);
+    if (world) hipLaunchKernelGGL(k_fill_u8, dim3(cdiv(count, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream, s->wdirty, (uint8_t)1, first, count);
+    HIP_TRY(s->ctx, hipGetLastError());
+    return YH_OK;
+}
+
+extern "C" int yh_compose(yh_scene* s, float* const planes[16], uint64_t first, uint64_t count) {
+    if (int rc = check_range(s, "yh_compose", first, count)) return rc;
+    ARG_TRY(s->ctx, planes, "yh_compose: planes is NULL");
+    if (s->desc.local_kind != YH_LOCAL_TRS) return fail(s->ctx, YH_ERR_STATE, "yh_compose: scene holds Mat4 locals");
+    if (count == 0) return YH_OK;
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    if (int rc = sync_scene(s)) return rc;
+    const uint64_t chunk = std::min<uint64_t>(count, YH_AOS_CHUNK);
+    if (int rc = ensure_staging(s, chunk * 64)) return rc;
+    for (uint64_t done = 0; done < count; done += chunk) {
+        const uint64_t c = std::min<uint64_t>(chunk, count - done);
+        hipLaunchKernelGGL(k_compose, dim3(cdiv(c, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream, s->trs, (float*)s->staging,
+                           s->stride, chunk, first + done, c);
+        HIP_TRY(s->ctx, hipGetLastError());
+        HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
+        for (int p = 0; p < 16; ++p) {
+            ARG_TRY(s->ctx, planes[p], "yh_compose: plane pointer is NULL");
+            HIP_TRY(s->ctx, hipMemcpy(planes[p] + done, (float*)s->staging + (uint64_t)p * chunk, c * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    return YH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ frame
+template <int BOUNDS>
+static void launch_trs(int G, dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a) {
+    switch (G) {
+        case 1: hipLaunchKernelGGL((k_frame_trs<1, BOUNDS>), grid, dim3(YH_BLOCK), lds, st, a); break;
+        case 2: hipLaunchKernelGGL((k_frame_trs<2, BOUNDS>), grid, dim3(YH_BLOCK), lds, st, a); break;
+        case 3:
+        case 4: hipLaunchKernelGGL((k_frame_trs<4, BOUNDS>), grid, dim3(YH_BLOCK), lds, st, a); break;
+        default: hipLaunchKernelGGL((k_frame_trs<8, BOUNDS>), grid, dim3(YH_BLOCK), lds, st, a); break;
+    }
+}
+
+static int ensure_kev(yh_scene* s) {
+    if (!s->kev.empty()) return YH_OK;
+    s->kev.assign(2 * YH_TIMING_RING, nullptr);
+    s->kev_group.assign(YH_TIMING_RING, 0);
+    for (auto& e : s->kev) HIP_TRY(s->ctx, hipEventCreate(&e));
+    return YH_OK;
+}
+
+extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uint32_t flags) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_frame: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    if (!s->have_hierarchy) return fail(ctx, YH_ERR_STATE, "yh_frame: call yh_upload_hierarchy first");
+    if (flags & YH_FRAME_ORDERED) return fail(ctx, YH_ERR_UNSUPPORTED, "yh_frame: YH_FRAME_ORDERED is not implemented yet");
+    const bool cull = !(flags & YH_FRAME_NO_CULL) && s->desc.bounds_kind != YH_BOUNDS_NONE && n_frusta > 0;
+    if (cull) {
+        ARG_TRY(ctx, planes, "yh_frame: planes is NULL");
+        ARG_TRY(ctx, n_frusta <= s->desc.n_frusta, "yh_frame: n_frusta exceeds the scene's draw lists");
+        if (s->desc.bounds_kind == YH_BOUNDS_MESH_TABLE && s->n_meshes == 0)
+            return fail(ctx, YH_ERR_STATE, "yh_frame: mesh table not uploaded");
+    }
+    if (s->desc.local_kind == YH_LOCAL_TRS && !(flags & YH_FRAME_ALL_DIRTY))
+        return fail(ctx, YH_ERR_UNSUPPORTED, "yh_frame: TRS scenes recompute every entity; pass YH_FRAME_ALL_DIRTY");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+
+    FrameArgs a;
+    memset(&a, 0, sizeof a);
+    a.trs = s->trs;
+    a.lmat = s->lmat;
+    a.parent = s->parent;
+    a.bounds = s->bounds;
+    a.mesh_id = s->mesh_id;
+    a.world = s->world;
+    a.ldirty = s->ldirty;
+    a.wdirty = s->wdirty;
+    a.counts = s->counts;
+    for (uint32_t f = 0; f < YH_MAX_FRUSTA; ++f) a.draw[f] = s->draw[f];
+    a.stride = s->stride;
+    a.draw_cap = s->draw_cap;
+    a.n_frusta = cull ? n_frusta : 0;
+    a.id_base = s->desc.id_base;
+    a.n_meshes = s->n_meshes;
+    memcpy(a.root, s->root, sizeof a.root);
+    if (cull) memcpy(a.planes, planes, (size_t)n_frusta * 24 * sizeof(float));
+    const int bounds = cull ? (int)s->desc.bounds_kind : 0;
+    const size_t lds = (32 + (size_t)a.n_frusta * YH_TILE) * sizeof(uint32_t);
+
+    HIP_TRY(ctx, hipEventRecord(s->ev0, st));
+    HIP_TRY(ctx, hipMemsetAsync(s->counts, 0, 2 * YH_MAX_FRUSTA * 4, st));
+    uint32_t launches = 0;
+    if (s->kernel_timing)
+        if (int rc = ensure_kev(s)) return rc;
+
+    auto time_begin = [&](uint32_t group) -> int {
+        if (s->kernel_timing && s->kev_used < YH_TIMING_RING) {
+            s->kev_group[s->kev_used] = group;
+            HIP_TRY(ctx, hipEventRecord(s->kev[2 * s->kev_used], st));
+        }
+        return YH_OK;
+    };
+    auto time_end = [&]() -> int {
+        if (s->kernel_timing && s->kev_used < YH_TIMING_RING) {
+            HIP_TRY(ctx, hipEventRecord(s->kev[2 * s->kev_used + 1], st));
+            ++s->kev_used;
+        }
+        return YH_OK;
+    };
+
+    if (s->desc.local_kind == YH_LOCAL_TRS) {
+        for (uint32_t gi = 0; gi < s->groups.size(); ++gi) {
+            const LevelGroup g = s->groups[gi];
+            a.begin = s->level_offsets[g.lo];
+            a.end = s->level_offsets[g.hi + 1];
+            if (a.end == a.begin) continue;
+            a.has_base = g.lo > 0;
+            for (uint32_t j = 0; j < YH_MAX_GROUP; ++j)
+                a.lvl_begin[j] = (g.lo + 1 + j <= g.hi) ? s->level_offsets[g.lo + 1 + j] : 0xFFFFFFFFu;
+            const dim3 grid(cdiv((uint64_t)a.end - a.begin, YH_TILE));
+            const int G = (int)(g.hi - g.lo + 1);
+            if (int rc = time_begin(gi)) return rc;
+            if (bounds == 0) launch_trs<0>(G, grid, lds, st, a);
+            else if (bounds == 1) launch_trs<1>(G, grid, lds, st, a);
+            else launch_trs<2>(G, grid, lds, st, a);
+            HIP_TRY(ctx, hipGetLastError());
+            if (int rc = time_end()) return rc;
+            ++launches;
+        }
+    } else {
+        if (flags & YH_FRAME_ALL_DIRTY) HIP_TRY(ctx, hipMemsetAsync(s->ldirty, 1, s->stride, st));
+        for (uint32_t k = 0; k < s->desc.n_levels; ++k) {
+            a.begin = s->level_offsets[k];
+            a.end = s->level_offsets[k + 1];
+            if (a.end == a.begin) continue;
+            a.has_base = k > 0;
+            const dim3 grid(cdiv((uint64_t)a.end - a.begin, YH_TILE));
+            if (int rc = time_begin(k)) return rc;
+            if (bounds == 0) hipLaunchKernelGGL((k_level_mat4<0>), grid, dim3(YH_BLOCK), lds, st, a, s->root_dirty);
+            else if (bounds == 1) hipLaunchKernelGGL((k_level_mat4<1>), grid, dim3(YH_BLOCK), lds, st, a, s->root_dirty);
+            else hipLaunchKernelGGL((k_level_mat4<2>), grid, dim3(YH_BLOCK), lds, st, a, s->root_dirty);
+            HIP_TRY(ctx, hipGetLastError());
+            if (int rc = time_end()) return rc;
+            ++launches;
+        }
+        // PostWorldTransform / PostLocalTransform (PostTransformSystem.zig:12-37)
+        hipLaunchKernelGGL(k_clear_dirty, dim3(cdiv(s->stride / 4, YH_BLOCK)), dim3(YH_BLOCK), 0, st, (uint32_t*)s->ldirty,
+                           (uint32_t*)s->wdirty, s->stride / 4);
+        HIP_TRY(ctx, hipGetLastError());
+        ++launches;
+    }
+    s->root_dirty = 0;  // the world sweep clears the root's flag too
+    HIP_TRY(ctx, hipMemcpyAsync(s->h_counts, s->counts, 2 * YH_MAX_FRUSTA * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipEventRecord(s->ev1, st));
+    s->frame_pending = true;
+    s->last_n_frusta = a.n_frusta;
+    s->last_launches = launches;
+    ++s->frames;
+    if (!(flags & YH_FRAME_ASYNC)) return sync_scene(s);
+    return YH_OK;
+}
+
+extern "C" int yh_get_counts(yh_scene* s, uint32_t* counts, uint32_t* boundary_counts) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_get_counts: scene is NULL");
+    if (s->frame_pending)
+        if (int rc = sync_scene(s)) return rc;
+    for (uint32_t f = 0; f < s->last_n_frusta; ++f) {
+        if (counts) counts[f] = s->h_counts[f];
+        if (boundary_counts) boundary_counts[f] = s->h_counts[YH_MAX_FRUSTA + f];
+    }
+    return YH_OK;
+}
+
+extern "C" int yh_get_draw_list(yh_scene* s, uint32_t frustum, uint32_t* out, uint64_t cap, uint64_t* written) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_get_draw_list: scene is NULL");
+    ARG_TRY(s->ctx, frustum < s->last_n_frusta, "yh_get_draw_list: frustum index out of range");
+    if (s->frame_pending)
+        if (int rc = sync_scene(s)) return rc;
+    const uint64_t c = s->h_counts[frustum];
+    if (written) *written = c;
+    if (c > s->draw_cap)
+        return fail(s->ctx, YH_ERR_CAPACITY, "yh_get_draw_list: %llu visible entities exceed the scene's draw capacity %llu",
+                    (unsigned long long)c, (unsigned long long)s->draw_cap);
+    if (c > cap || (c && !out))
+        return fail(s->ctx, YH_ERR_CAPACITY, "yh_get_draw_list: buffer of %llu entries is too small, %llu required",
+                    (unsigned long long)cap, (unsigned long long)c);
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    if (c) HIP_TRY(s->ctx, hipMemcpy(out, s->draw[frustum], c * 4, hipMemcpyDeviceToHost));
+    return YH_OK;
+}
+
+extern "C" int yh_timings(yh_scene* s, yh_timing* out) {
+    if (!s || !out) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_timings: NULL argument");
+    memset(out, 0, sizeof *out);
+    out->frames = s->frames;
+    out->n_launches = s->last_launches;
+    out->n_groups = (uint32_t)s->groups.size();
+    if (s->frames == 0) return YH_OK;
+    if (int rc = sync_scene(s)) return rc;
+    HIP_TRY(s->ctx, hipEventElapsedTime(&out->last_frame_ms, s->ev0, s->ev1));
+    // per-launch events (when enabled): mean duration of the slowest group since the last call
+    if (s->kernel_timing && s->kev_used) {
+        double sum[YH_MAX_LEVELS] = {0};
+        uint32_t cnt[YH_MAX_LEVELS] = {0};
+        for (uint32_t i = 0; i < s->kev_used; ++i) {
+            float ms = 0;
+            HIP_TRY(s->ctx, hipEventElapsedTime(&ms, s->kev[2 * i], s->kev[2 * i + 1]));
+            const uint32_t g = s->kev_group[i] % YH_MAX_LEVELS;
+            sum[g] += ms;
+            cnt[g]++;
+        }
+        double best = 0;
+        for (uint32_t g = 0; g < YH_MAX_LEVELS; ++g)
+            if (cnt[g] && sum[g] / cnt[g] > best) best = sum[g] / cnt[g];
+        out->last_kernel_ms = (float)best;
+        s->kev_used = 0;
+    }
+    return YH_OK;
+}
+
+// Not part of the reference-facing boundary: per-launch HIP-event timing for the measurement harness.
+extern "C" int yh_scene_set_kernel_timing(yh_scene* s, int enable) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_scene_set_kernel_timing: scene is NULL");
+    s->kernel_timing = enable != 0;
+    s->kev_used = 0;
+    return YH_OK;
+}
+
+// Level groups of the current plan: writes up to cap (lo, hi, first_entity, end_entity) quadruples.
+extern "C" int yh_scene_get_groups(yh_scene* s, uint32_t* quads, uint32_t cap, uint32_t* n_groups) {
+    if (!s || !n_groups) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_scene_get_groups: NULL argument");
+    if (!s->have_hierarchy) return fail(s->ctx, YH_ERR_STATE, "yh_scene_get_groups: no hierarchy");
+    if (s->desc.local_kind == YH_LOCAL_MAT4) {
+        *n_groups = s->desc.n_levels;
+        for (uint32_t k = 0; k < s->desc.n_levels && k < cap && quads; ++k) {
+            quads[4 * k] = quads[4 * k + 1] = k;
+            quads[4 * k + 2] = s->level_offsets[k];
+            quads[4 * k + 3] = s->level_offsets[k + 1];
+        }
+        return YH_OK;
+    }
+    *n_groups = (uint32_t)s->groups.size();
+    for (uint32_t i = 0; i < s->groups.size() && i < cap && quads; ++i) {
+        quads[4 * i] = s->groups[i].lo;
+        quads[4 * i + 1] = s->groups[i].hi;
+        quads[4 * i + 2] = s->level_offsets[s->groups[i].lo];
+        quads[4 * i + 3] = s->level_offsets[s->groups[i].hi + 1];
+    }
+    return YH_OK;
+}
+
+// Mean device time per level group from the per-launch events recorded since the last call.
+extern "C" int yh_scene_get_group_timings(yh_scene* s, float* mean_ms, uint32_t* samples, uint32_t cap) {
+    if (!s || !mean_ms) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_scene_get_group_timings: NULL argument");
+    if (int rc = sync_scene(s)) return rc;
+    std::vector<double> sum(cap, 0.0);
+    std::vector<uint32_t> cnt(cap, 0);
+    for (uint32_t i = 0; i < s->kev_used; ++i) {
+        float ms = 0;
+        HIP_TRY(s->ctx, hipEventElapsedTime(&ms, s->kev[2 * i], s->kev[2 * i + 1]));
+        const uint32_t g = s->kev_group[i];
+        if (g < cap) {
+            sum[g] += ms;
+            cnt[g]++;
+        }
+    }
+    for (uint32_t g = 0; g < cap; ++g) {
+        mean_ms[g] = cnt[g] ? (float)(sum[g] / cnt[g]) : 0.0f;
+        if (samples) samples[g] = cnt[g];
+    }
+    s->kev_used = 0;
+    return YH_OK;
+}
+
+// ------------------------------------------------------------------------------------ frustum helpers
+extern "C" void yh_mat4_mul(const float a[16], const float b[16], float out[16]) {
+    M4 x, y;
+    memcpy(x.v, a, 64);
+    memcpy(y.v, b, 64);
+    const M4 r = m4_mul(x, y);
+    memcpy(out, r.v, 64);
+}
+
+// engine/math3d.zig:649-659
+extern "C" void yh_perspective(float fovy_rad, float aspect, float near_z, float far_z, float out[16]) {
+    const float f = 1.0f / tanf(fovy_rad / 2.0f);
+    memset(out, 0, 64);
+    out[0] = f / aspect;
+    out[5] = f;
+    out[10] = far_z / (near_z - far_z);
+    out[11] = -1.0f;
+    out[14] = -(far_z * near_z) / (far_z - near_z);
+}
+
+// engine/math3d.zig:661-683
+extern "C" void yh_orthographic(float l, float r, float b, float t, float n, float f, float out[16]) {
+    memset(out, 0, 64);
+    out[0] = 2.0f / (r - l);
+    out[5] = 2.0f / (b - t);
+    out[10] = 1.0f / (n - f);
+    out[12] = -(r + l) / (r - l);
+    out[13] = -(b + t) / (b - t);
+    out[14] = n / (n - f);
+    out[15] = 1.0f;
+}
+
+static void h_normalized(const float a[3], float o[3]) {  // math3d.zig:116-123
+    const float l = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    if (l > 0.0f) {
+        o[0] = a[0] / l;
+        o[1] = a[1] / l;
+        o[2] = a[2] / l;
+    } else {
+        o[0] = o[1] = o[2] = 0.0f;
+    }
+}
+static float h_dot(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void h_cross(const float a[3], const float b[3], float o[3]) {
+    const float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x;
+    o[1] = y;
+    o[2] = z;
+}
+
+// engine/math3d.zig:991-1021
+extern "C" void yh_look_at(const float eye[3], const float at[3], const float up[3], float out[16]) {
+    float x[3], y[3], z[3], tmp[3] = {eye[0] - at[0], eye[1] - at[1], eye[2] - at[2]};
+    h_normalized(tmp, z);
+    h_normalized(up, y);
+    h_cross(y, z, tmp);
+    h_normalized(tmp, x);
+    h_cross(z, x, tmp);
+    h_normalized(tmp, y);
+    const float m[16] = {x[0], y[0], z[0], 0.0f, x[1], y[1], z[1], 0.0f, x[2], y[2], z[2], 0.0f,
+                         -h_dot(x, eye), -h_dot(y, eye), -h_dot(z, eye), 1.0f};
+    memcpy(out, m, 64);
+}
+
+// Gribb-Hartmann, depth 0..1: L,R,B,T,N,F, each divided by |n|.
+extern "C" void yh_extract_planes(const float vp[16], float planes_out[24]) {
+    float p[6][4];
+    for (int c = 0; c < 4; ++c) {
+        const float r0 = vp[c * 4 + 0], r1 = vp[c * 4 + 1], r2 = vp[c * 4 + 2], r3 = vp[c * 4 + 3];
+        p[0][c] = r3 + r0;
+        p[1][c] = r3 - r0;
+        p[2][c] = r3 + r1;
+        p[3][c] = r3 - r1;
+        p[4][c] = r2;
+        p[5][c] = r3 - r2;
+    }
+    for (int i = 0; i < 6; ++i) {
+        const float len = sqrtf(p[i][0] * p[i][0] + p[i][1] * p[i][1] + p[i][2] * p[i][2]);
+        for (int c = 0; c < 4; ++c) planes_out[i * 4 + c] = p[i][c] / len;
+    }
+}
+
+// ------------------------------------------------------------------------------------ synthetic scenes
+extern "C" int yh_scene_fill_synthetic(yh_scene* s, const yh_synth_desc* d) {
+    if (!s || !d) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_scene_fill_synthetic: NULL argument");
+    if (!s->have_hierarchy) return fail(s->ctx, YH_ERR_STATE, "yh_scene_fill_synthetic: upload the hierarchy first");
+    if (s->desc.local_kind != YH_LOCAL_TRS) return fail(s->ctx, YH_ERR_STATE, "yh_scene_fill_synthetic: TRS scenes only");
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    const bool table = s->desc.bounds_kind == YH_BOUNDS_MESH_TABLE;
+    if (table) {
+        const uint32_t nm = s->desc.max_meshes;
+        std::vector<float> t((size_t)nm * 6);
+        for (uint32_t m = 0; m < nm; ++m)
+            for (int c = 0; c < 3; ++c) {
+                const float h = yh_synth_uniform(d->seed, 16u + (uint32_t)c, m, 0.25f, 2.0f);
+                t[m * 6 + c] = -h;
+                t[m * 6 + 3 + c] = h;
+            }
+        if (int rc = yh_upload_mesh_aabbs(s, t.data(), nm)) return rc;
+    }
+    hipLaunchKernelGGL(k_synth, dim3(cdiv(s->n, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream, s->trs,
+                       s->desc.bounds_kind == YH_BOUNDS_PER_ENTITY ? s->bounds : (float*)nullptr,
+                       table ? s->mesh_id : (uint32_t*)nullptr, table ? s->n_meshes : 1u, s->stride, s->n,
+                       (uint64_t)s->level_offsets[1], d->seed, d->index_base);
+    HIP_TRY(s->ctx, hipGetLastError());
+    return sync_scene(s);
+}
+
+// -------------------------------------------------------------------------------------------- RCCL
+// RCCL is loaded on demand so that single-GPU users never depend on it.  Types are kept opaque; the
+// enum values below are RCCL's (rccl.h: ncclUint32 = 3, ncclSuccess = 0).
+typedef struct {
+    char internal[YH_UNIQUE_ID_BYTES];
+} yh_nccl_id;
+typedef int (*fn_GetUniqueId)(yh_nccl_id*);
+typedef int (*fn_CommInitRank)(void**, int, yh_nccl_id, int);
+typedef int (*fn_CommDestroy)(void*);
+typedef int (*fn_AllGather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_Group)(void);
+typedef const char* (*fn_GetErrorString)(int);
+
+static struct {
+    void* lib;
+    fn_GetUniqueId GetUniqueId;
+    fn_CommInitRank CommInitRank;
+    fn_CommDestroy CommDestroy;
+    fn_AllGather AllGather;
+    fn_Broadcast Broadcast;
+    fn_Group GroupStart, GroupEnd;
+    fn_GetErrorString GetErrorString;
+} g_rccl;
+
+static int rccl_load(yh_ctx* ctx) {
+    if (g_rccl.lib) return YH_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) return fail(ctx, YH_ERR_RCCL, "RCCL not found: %s", dlerror());
+#define SYM(field, name)                                                              \
+    g_rccl.field = (decltype(g_rccl.field))dlsym(lib, name);                          \
+    if (!g_rccl.field) return fail(ctx, YH_ERR_RCCL, "RCCL symbol %s missing", name);
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(AllGather, "ncclAllGather")
+    SYM(Broadcast, "ncclBroadcast")
+    SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl.lib = lib;
+    return YH_OK;
+}
+
+#define RCCL_TRY(ctx, call)                                                                                   \
+    do {                                                                                                      \
+        int r_ = (call);                                                                                      \
+        if (r_ != 0) return fail((ctx), YH_ERR_RCCL, "%s failed: %s", #call, g_rccl.GetErrorString(r_));      \
+    } while (0)
+
+extern "C" int yh_comm_unique_id(void* out_id) {
+    if (!out_id) return fail(nullptr, YH_ERR_BAD_ARG, "yh_comm_unique_id: out_id is NULL");
+    if (int rc = rccl_load(nullptr)) return rc;
+    yh_nccl_id id;
+    memset(&id, 0, sizeof id);
+    RCCL_TRY(nullptr, g_rccl.GetUniqueId(&id));
+    memcpy(out_id, &id, sizeof id);
+    return YH_OK;
+}
+
+extern "C" int yh_comm_init(yh_ctx* ctx, int n_ranks, int rank, const void* unique_id) {
+    if (!ctx || !unique_id) return fail(ctx, YH_ERR_BAD_ARG, "yh_comm_init: NULL argument");
+    ARG_TRY(ctx, n_ranks >= 1 && rank >= 0 && rank < n_ranks, "yh_comm_init: bad rank / n_ranks");
+    if (ctx->comm) return fail(ctx, YH_ERR_STATE, "yh_comm_init: communicator already initialised");
+    if (int rc = rccl_load(ctx)) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    yh_nccl_id id;
+    memcpy(&id, unique_id, sizeof id);
+    RCCL_TRY(ctx, g_rccl.CommInitRank(&ctx->comm, n_ranks, id, rank));
+    ctx->n_ranks = n_ranks;
+    ctx->rank = rank;
+    return YH_OK;
+}
+
+extern "C" void yh_comm_destroy(yh_ctx* ctx) {
+    if (ctx && ctx->comm && g_rccl.CommDestroy) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        g_rccl.CommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+        ctx->n_ranks = 1;
+        ctx->rank = 0;
+    }
+}
+
+extern "C" int yh_allgather_draw_lists(yh_scene* s, uint32_t* all_counts) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_allgather_draw_lists: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    if (!ctx->comm) return fail(ctx, YH_ERR_STATE, "yh_allgather_draw_lists: call yh_comm_init first");
+    if (s->frames == 0) return fail(ctx, YH_ERR_STATE, "yh_allgather_draw_lists: no frame has run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int R = ctx->n_ranks;
+    const uint32_t F = s->last_n_frusta;
+    if (!s->d_all_counts) {
+        HIP_TRY(ctx, hipMalloc((void**)&s->d_all_counts, (size_t)R * YH_MAX_FRUSTA * 4));
+        HIP_TRY(ctx, hipHostMalloc((void**)&s->h_all_counts, (size_t)R * YH_MAX_FRUSTA * 4, hipHostMallocDefault));
+    }
+    hipStream_t st = ctx->stream;
+    // (1) per-rank visible counts: 8 x u32 per rank
+    RCCL_TRY(ctx, g_rccl.AllGather(s->counts, s->d_all_counts, YH_MAX_FRUSTA, /*ncclUint32*/ 3, ctx->comm, st));
+    HIP_TRY(ctx, hipMemcpyAsync(s->h_all_counts, s->d_all_counts, (size_t)R * YH_MAX_FRUSTA * 4, hipMemcpyDeviceToHost, st));
+    if (int rc = sync_scene(s)) return rc;
+    // (2) exact-size lists at prefix-sum offsets
+    for (uint32_t f = 0; f < F; ++f) {
+        uint64_t total = 0;
+        for (int r = 0; r < R; ++r) total += s->h_all_counts[r * YH_MAX_FRUSTA + f];
+        if (total > s->gathered_cap[f]) {
+            if (s->gathered[f]) HIP_TRY(ctx, hipFree(s->gathered[f]));
+            s->gathered[f] = nullptr;
+            s->gathered_cap[f] = 0;
+            const uint64_t cap = total + total / 2 + 1024;
+            HIP_TRY(ctx, hipMalloc((void**)&s->gathered[f], cap * 4));
+            s->gathered_cap[f] = cap;
+        }
+        s->gathered_len[f] = total;
+    }
+    for (int r = 0; r < R; ++r)
+        for (uint32_t f = 0; f < F; ++f)
+            if (s->h_all_counts[r * YH_MAX_FRUSTA + f] > s->draw_cap)
+                return fail(ctx, YH_ERR_CAPACITY, "yh_allgather_draw_lists: rank %d frustum %u overflowed its draw list", r, f);
+    RCCL_TRY(ctx, g_rccl.GroupStart());
+    for (uint32_t f = 0; f < F; ++f) {
+        uint64_t off = 0;
+        for (int r = 0; r < R; ++r) {
+            const uint64_t c = s->h_all_counts[r * YH_MAX_FRUSTA + f];
+            if (c) {
+                int rc = g_rccl.Broadcast(s->draw[f], s->gathered[f] + off, c, /*ncclUint32*/ 3, r, ctx->comm, st);
+                if (rc != 0) {
+                    g_rccl.GroupEnd();
+                    return fail(ctx, YH_ERR_RCCL, "ncclBroadcast failed: %s", g_rccl.GetErrorString(rc));
+                }
+            }
+            off += c;
+        }
+    }
+    RCCL_TRY(ctx, g_rccl.GroupEnd());
+    if (int rc = sync_scene(s)) return rc;
+    if (all_counts)
+        for (int r = 0; r < R; ++r)
+            for (uint32_t f = 0; f < F; ++f) all_counts[r * F + f] = s->h_all_counts[r * YH_MAX_FRUSTA + f];
+    return YH_OK;
+}
+
+extern "C" int yh_get_gathered_draw_list(yh_scene* s, uint32_t frustum, uint32_t* out, uint64_t cap, uint64_t* written) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_get_gathered_draw_list: scene is NULL");
+    ARG_TRY(s->ctx, frustum < s->last_n_frusta, "yh_get_gathered_draw_list: frustum index out of range");
+    const uint64_t c = s->gathered_len[frustum];
+    if (written) *written = c;
+    if (c > cap || (c && !out))
+        return fail(s->ctx, YH_ERR_CAPACITY, "yh_get_gathered_draw_list: buffer of %llu entries is too small, %llu required",
+                    (unsigned long long)cap, (unsigned long long)c);
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    if (c) HIP_TRY(s->ctx, hipMemcpy(out, s->gathered[frustum], c * 4, hipMemcpyDeviceToHost));
+    return YH_OK;
+}
