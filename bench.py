@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""bench.py — Mentities/s transformed + culled per frame, % of the HBM roofline, CPU systems beside it.
+
+A "step" is one frame of the hot path (compose -> level-ordered propagate -> cull + compact, count read-back)
+over one synthetic scene that is already resident in HBM.  One process per GPU:
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workloads (BASELINE.json configs): cfg2 (default; 1M entities, random 8-level tree, 1 frustum, per GPU),
+cfg3 (16M flat, 5 frusta), cfg4 (12.5M-entity 8-level shard per GPU = 100M on 8), cfg5 (256M flat instanced
+AABBs, split over the GPUs).  With N > 1 every rank owns a subtree-closed shard (its own tree, global ids
+offset by shard_base) and each frame ends with the RCCL all-gather of counts and draw lists.  Scaling is
+weak for cfg2/cfg3/cfg4 (per-GPU shard fixed) and strong for cfg5.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+WORKLOADS = {
+    # name: (entities per GPU or total, levels, frusta, bounds_kind, scaling)
+    "cfg2": dict(n=1_000_000, levels=8, frusta="main", bounds=1, scaling="weak",
+                 desc="1M entities, random 8-level hierarchy, single camera frustum (BASELINE configs[1])"),
+    "cfg3": dict(n=16 * 1024 * 1024, levels=1, frusta="main+casc", bounds=1, scaling="weak",
+                 desc="16M flat entities, 4 shadow cascades + main camera (BASELINE configs[2])"),
+    "cfg4": dict(n=12_500_000, levels=8, frusta="main", bounds=1, scaling="weak",
+                 desc="12.5M-entity 8-level subtree-closed shard per GPU = 100M on 8 GPUs (BASELINE configs[3])"),
+    "cfg5": dict(n=256 * 1000 * 1000, levels=1, frusta="main", bounds=2, scaling="strong",
+                 desc="256M flat instances, 16 instanced AABBs, split over the GPUs (BASELINE configs[4])"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--entities", type=int, default=0, help="override entities per GPU")
+    ap.add_argument("--grouping", type=int, default=0, help="levels per launch (0 = automatic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(wl, lo, parent, first, end, visible_per_entity_sum):
+    """compulsory HBM bytes of a fully fused pass over entities [first, end).
+    reads: TRS 40 B + parent index 4 B (levels > 0) + AABB 24 B (or 4 B mesh id) + 64 B per DISTINCT parent per
+    level; writes: world 64 B + 4 B per emitted draw index."""
+    from yume_amd import synth
+
+    n = end - first
+    b = n * (40 + 64) + n * (24 if wl["bounds"] == 1 else 4)
+    n_child = end - max(first, int(lo[1]))
+    if n_child > 0:
+        b += 4 * n_child
+        # distinct parents of the levels that intersect [first, end)
+        for k in range(1, len(lo) - 1):
+            a, z = max(first, int(lo[k])), min(end, int(lo[k + 1]))
+            if z > a:
+                p = parent[a:z]
+                b += 64 * int(np.count_nonzero(np.diff(p)) + 1)
+    b += 4 * visible_per_entity_sum * n
+    return float(b)
+
+
+def cpu_baseline(args, wl, n, lo, parent, planes, seconds):
+    """The reference CPU systems (oracle port: AoS 68-byte columns, one batch per table, forward branch on every
+    row + both dirty sweeps, then the cull), single thread as the reference runs them, on the host cores of
+    this box.  Only this leg touches oracle/."""
+    from oracle import pyoracle as oracle
+
+    n_s = min(n, 1_000_000)  # bounded sample: at most 1M entities per CPU frame
+    if n_s != n:
+        lo_s = oracle.synth_level_offsets(n_s, len(lo) - 1)
+        par_s = oracle.synth_parents(lo_s)
+    else:
+        lo_s, par_s = lo, parent
+    trs = oracle.synth_trs(n_s, int(lo_s[1]))
+    if wl["bounds"] == 1:
+        bounds, mesh = oracle.synth_aabb(n_s), None
+    else:
+        bounds, mesh = oracle.synth_mesh_table(16), oracle.synth_mesh_ids(n_s, 16)
+    local = oracle.compose_batch(trs)
+    world = np.zeros(n_s, oracle.T68)
+    world["m"][:, [0, 5, 10, 15]] = 1
+    root = oracle.identity68()
+
+    def frame(threads):
+        local["dirty"] = 1  # the benchmark marks every LocalTransform dirty (untimed)
+        t0 = time.perf_counter()
+        oracle.frame_aos68(world, local, par_s, lo_s, root, threads)
+        oracle.cull(world, bounds, planes, mesh_id=mesh, n_threads=threads)
+        return time.perf_counter() - t0
+
+    out = {}
+    for key, threads, budget in (("cpu_baseline", 1, seconds), ("cpu_baseline_mt", min(16, os.cpu_count() or 1), seconds / 3)):
+        for _ in range(2):
+            frame(threads)
+        times = []
+        t_end = time.perf_counter() + budget
+        while time.perf_counter() < t_end or len(times) < 3:
+            times.append(frame(threads))
+        med = float(np.median(times))
+        out[key] = {
+            "value": round(n_s / med / 1e6, 3),
+            "unit": "Mentities/s",
+            "cores": threads,
+            "kind": "port",
+            "ns_per_entity": round(med / n_s * 1e9, 2),
+            "sample": f"{len(times)} frames of a {n_s}-entity {len(lo_s) - 1}-level scene, {planes.shape[0]} frusta "
+                      f"(median; gcc -O2 -ffp-contract=off; AoS-68 propagate + 2 dirty sweeps + cull)"
+                      + ("" if n_s == n else f"; sampled from the {n}-entity workload"),
+        }
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_size}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        if world_size == 1 and args.gpus > 1:
+            sys.exit(2)
+
+    import torch
+
+    from yume_amd import Context, Scene, _lib, synth
+
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = WORKLOADS[args.workload]
+    n = args.entities or wl["n"]
+    if wl["scaling"] == "strong":
+        n = n // world_size
+    total = n * world_size
+    planes = synth.main_camera_planes().reshape(1, 24)
+    if wl["frusta"] == "main+casc":
+        planes = np.concatenate([planes, synth.cascade_planes()])
+    F = planes.shape[0]
+
+    ctx = Context(local_rank)
+    info = ctx.device_info()
+    lo = synth.level_offsets(n, wl["levels"])
+    parent = synth.parents(lo, index_base=rank * n)
+    scene = Scene(ctx, n, n_levels=wl["levels"], n_frusta=F, bounds_kind=wl["bounds"],
+                  max_meshes=16 if wl["bounds"] == 2 else 0, id_base=rank * n)
+    scene.upload_hierarchy(parent, lo)
+    scene.fill_synthetic(index_base=rank * n)  # inputs generated straight into HBM
+    scene.set_grouping(args.grouping)
+    flags = _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC
+
+    collective = "none"
+    if world_size > 1:
+        ids = [Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(world_size, rank, ids[0])
+        collective = "rccl allgather(counts) + grouped bcast(lists), direct"
+
+    def step():
+        scene.frame(planes, flags)
+        if world_size > 1:
+            scene.allgather_draw_lists()
+
+    def barrier():
+        ctx.wait()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    scene.set_kernel_timing(not args.no_kernel_events)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: mean launch duration from the HIP events recorded inside the timed region
+    groups = scene.groups()
+    roofline = None
+    counts, bcounts = scene.counts()
+    vis_sum = float(counts[:F].sum()) / n
+    if not args.no_kernel_events:
+        ms, samples = scene.group_timings()
+        ms = ms.astype(np.float64)
+        g = int(np.argmax(ms[: len(groups)]))
+        first, end = int(groups[g][2]), int(groups[g][3])
+        b = algorithmic_bytes(wl, lo, parent, first, end, vis_sum)
+        achieved = b / (ms[g] * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "kernel": f"k_frame_trs levels {int(groups[g][0])}..{int(groups[g][1])}",
+            "kernel_entities": end - first, "kernel_ms": round(float(ms[g]), 5), "kernel_samples": int(samples[g]),
+            "algorithmic_bytes_per_launch": b, "algorithmic_bytes_per_entity": round(b / (end - first), 2),
+            "launch_ms_all": [round(float(x), 5) for x in ms[: len(groups)]],
+            "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
+        }
+    scene.set_kernel_timing(False)
+
+    # un-instrumented pass of the same K steps (reported beside, never as `value`)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed_plain = time.perf_counter() - t1
+    if dist is not None:
+        t = torch.tensor([elapsed_plain], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_plain = float(t.item())
+
+    # per-frame latency with a host sync every frame (what an engine that reads counts each frame sees)
+    lat = []
+    for _ in range(min(50, args.steps)):
+        a = time.perf_counter()
+        scene.frame(planes, _lib.YH_FRAME_ALL_DIRTY)
+        if world_size > 1:
+            scene.allgather_draw_lists()
+        lat.append(time.perf_counter() - a)
+
+    b_frame = algorithmic_bytes(wl, lo, parent, 0, n, vis_sum)
+    result = {
+        "metric": "Mentities/s transformed+culled per frame",
+        "value": round(total * args.steps / elapsed / 1e6, 2),
+        "unit": "Mentities/s",
+        "n_gpus": world_size,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": wl["scaling"],
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {wl['desc']}", "entities_per_gpu": n, "entities_total": total,
+                   "levels": wl["levels"], "frusta": F, "launches_per_frame": int(len(groups)),
+                   "level_groups": [[int(x) for x in q] for q in groups], "collective": collective,
+                   "device": info["name"], "arch": info["arch"]},
+        "roofline": roofline,
+        "frame_hbm_frac": round(b_frame * world_size / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBPS * world_size), 4),
+        "frame_algorithmic_bytes_per_entity": round(b_frame / n, 2),
+        "value_without_kernel_events": round(total * args.steps / elapsed_plain / 1e6, 2),
+        "frame_latency_ms_synced_median": round(float(np.median(lat)) * 1e3, 5),
+        "visible_fraction": [round(float(c) / n, 4) for c in counts[:F]],
+        "boundary_cases": [int(x) for x in bcounts[:F]],
+    }
+    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
+        result.update(cpu_baseline(args, wl, n, lo, parent, planes, args.cpu_seconds))
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    scene.close()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result, default=float), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -88,7 +88,7 @@ typedef struct yh_scene_desc {
 #define YH_FRAME_ORDERED     0x8u /* draw lists in ascending entity order (two-pass scan instead of atomics) */
 
 typedef struct yh_timing {
-    float last_frame_ms;    /* device time of the most recent completed frame (hipEvent)            */
+    float last_frame_ms;    /* device time of the most recent frame (hipEvent; 0 unless kernel timing is on) */
     float last_kernel_ms;   /* device time of its longest kernel launch                             */
     uint32_t n_launches;    /* kernel launches in that frame                                        */
     uint32_t n_groups;      /* level groups the hierarchy was cut into                              */

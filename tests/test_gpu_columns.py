@@ -1,0 +1,139 @@
+"""GPU parity of the drop-in column path: flecs 68-byte {Mat4, dirty} columns in, the literal three-branch
+rule of TransformSyncSystem.zig:60-73 + the PostTransform dirty reset on the device, columns out — checked
+frame after frame against the oracle's reference-faithful AoS system."""
+import numpy as np
+import pytest
+
+from .test_gpu_parity import assert_same_values
+
+pytestmark = pytest.mark.gpu
+
+
+def build(oracle, n, n_levels, seed=7):
+    lo = oracle.synth_level_offsets(n, n_levels)
+    par = oracle.synth_parents(lo, seed=seed)
+    trs = oracle.synth_trs(n, int(lo[1]), seed=seed)
+    bounds = oracle.synth_aabb(n, seed=seed)
+    local = oracle.compose_batch(trs)
+    world = np.zeros(n, oracle.T68)
+    world["m"][:, [0, 5, 10, 15]] = 1
+    world["dirty"] = 1
+    return lo, par, bounds, local, world
+
+
+def test_aos68_roundtrip(ctx, oracle):
+    from yume_amd import Scene, _lib
+
+    for n in (1, 255, 256, 257, 100_003):
+        rng = np.random.default_rng(n)
+        col = np.zeros(n, oracle.T68)
+        col["m"] = rng.standard_normal((n, 16)).astype(np.float32)
+        col["dirty"] = rng.integers(0, 2, n)
+        col["pad"] = rng.integers(0, 255, (n, 3))  # padding bytes are whatever flecs left there
+        with Scene(ctx, n, n_frusta=0, bounds_kind=0, local_kind=_lib.YH_LOCAL_MAT4) as s:
+            s.upload_flat()
+            s.upload_local_aos68(col)
+            s.upload_world_aos68(col[::-1].copy())
+            l = s.local_aos68()
+            w = s.world_aos68()
+            assert np.array_equal(l["m"].view(np.uint32), col["m"].view(np.uint32))
+            assert np.array_equal(l["dirty"], col["dirty"]) and not l["pad"].any()
+            assert np.array_equal(w["m"].view(np.uint32), col["m"][::-1].view(np.uint32))
+            assert np.array_equal(w["dirty"], col["dirty"][::-1])
+            # partial ranges
+            if n > 300:
+                s.upload_local_aos68(col[:100], first=200)
+                assert np.array_equal(s.local_aos68(200, 100)["m"], col["m"][:100])
+                assert np.array_equal(s.local_aos68(0, 200)["m"], col["m"][:200])
+
+
+def test_dirty_frames_match_reference_system(ctx, oracle):
+    """Six frames of edits: nothing dirty, local edits, world-only edits (inverse branch), a singular parent,
+    re-rooting — device columns must equal the oracle's after every frame, dirty bytes included."""
+    from yume_amd import Scene, _lib
+
+    n = 60_000
+    lo, par, bounds, local, world = build(oracle, n, 6)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    root = oracle.identity68()
+    rng = np.random.default_rng(11)
+    mins = np.ascontiguousarray(bounds[:, 0:3].T)
+    maxs = np.ascontiguousarray(bounds[:, 3:6].T)
+
+    with Scene(ctx, n, n_levels=6, n_frusta=1, local_kind=_lib.YH_LOCAL_MAT4) as s:
+        s.upload_hierarchy(par, lo)
+        s.upload_aabb(mins, maxs)
+        s.upload_local_aos68(local)
+        s.upload_world_aos68(world)
+
+        def step(tag):
+            oracle.frame_aos68(world, local, par, lo, root)
+            s.frame(planes, flags=0)
+            gw, gl = s.world_aos68(), s.local_aos68()
+            with np.errstate(all="ignore"):
+                assert_same_values(gw["m"], world["m"], f"{tag}: world")
+                assert_same_values(gl["m"], local["m"], f"{tag}: local")
+            assert not gw["dirty"].any() and not gl["dirty"].any(), tag
+            vis, bnd = oracle.cull(world, bounds, planes)
+            assert np.array_equal(np.sort(s.draw_list(0)), np.flatnonzero(vis[0]).astype(np.uint32)), tag
+            assert s.counts()[1][0] == np.count_nonzero(bnd[0])
+
+        step("frame 0 (everything dirty)")
+        step("frame 1 (nothing dirty)")
+
+        # local edits on random entities (inspector drag: Mat4.recompose + modified(LocalTransform))
+        idx = np.unique(rng.integers(0, n, 500))
+        for e in idx:
+            local["m"][e] = oracle.compose(rng.uniform(-5, 5, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+        local["dirty"][idx] = 1
+        s.upload_local_aos68(local)  # whole column, dirty bytes travel with it
+        step("frame 2 (local edits)")
+
+        # world-only edits (gizmo: SceneWindow.zig:334-351) -> inverse branch re-derives the local
+        idx = np.unique(rng.integers(int(lo[1]), n, 300))
+        for e in idx:
+            world["m"][e] = oracle.compose(rng.uniform(-50, 50, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+        world["dirty"][idx] = 1
+        s.upload_world_aos68(world)
+        step("frame 3 (world edits)")
+
+        # a singular parent: its children edited in world space take IDENTITY as the inverse
+        p = int(lo[1]) + 5
+        local["m"][p] = 0
+        local["dirty"][p] = 1
+        s.upload_local_aos68(local[p : p + 1], first=p)
+        step("frame 4 (singular parent, forward)")
+        kids = np.flatnonzero(par == p)
+        if kids.size:
+            world["dirty"][kids] = 1
+            s.mark_dirty(world=True, first=int(kids[0]), count=int(kids.size))  # siblings are contiguous
+            step("frame 5 (children of a singular parent, inverse -> identity)")
+
+        # re-rooting: root WorldTransform set -> dirty -> everything recomputes
+        root["m"][0] = oracle.compose([1, 2, 3], [0, 0.7071068, 0, 0.7071068], [2, 2, 2])
+        root["dirty"] = 1
+        s.set_root(root["m"][0])
+        step("frame 6 (root moved)")
+
+
+def test_mat4_all_dirty_equals_trs_path(ctx, oracle):
+    """The same scene through both device representations gives the same world matrices and draw lists."""
+    from yume_amd import Scene, _lib
+
+    n = 300_000
+    lo, par, bounds, local, world = build(oracle, n, 8, seed=oracle.SEED)
+    trs = oracle.synth_trs(n, int(lo[1]))
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    mins = np.ascontiguousarray(bounds[:, 0:3].T)
+    maxs = np.ascontiguousarray(bounds[:, 3:6].T)
+    with Scene(ctx, n, n_levels=8, n_frusta=1, local_kind=_lib.YH_LOCAL_MAT4) as a, \
+         Scene(ctx, n, n_levels=8, n_frusta=1) as b:
+        for s in (a, b):
+            s.upload_hierarchy(par, lo)
+            s.upload_aabb(mins, maxs)
+        a.upload_local_aos68(local)
+        b.upload_trs(trs)
+        a.frame(planes, flags=_lib.YH_FRAME_ALL_DIRTY)
+        b.frame(planes)
+        assert_same_values(a.world_soa(), b.world_soa(), "mat4 vs trs")
+        assert np.array_equal(np.sort(a.draw_list(0)), np.sort(b.draw_list(0)))

@@ -1,0 +1,333 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes -> libyume_hip.so), against the CPU
+oracle on the same seeded inputs.
+
+Bar: world matrices equal as IEEE values element for element (zero tolerance; the only freedom is the sign
+of a zero, see yh_math.hpp m4_compose) — far inside north_star's 1e-5 relative; visible-index SETS exact;
+boundary counts exact.  NaN positions must coincide.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 0.0  # north_star allows 1e-5 relative per element; we require equality
+
+
+def assert_same_values(got, exp, what=""):
+    got = np.asarray(got)
+    exp = np.asarray(exp)
+    assert got.shape == exp.shape, what
+    nan_g, nan_e = np.isnan(got), np.isnan(exp)
+    assert np.array_equal(nan_g, nan_e), f"{what}: NaN pattern differs"
+    ok = (got == exp) | nan_g
+    if not ok.all():
+        bad = np.argwhere(~ok)[0]
+        raise AssertionError(f"{what}: {np.count_nonzero(~ok)} elements differ, first at {tuple(bad)}: "
+                             f"{got[tuple(bad)]!r} vs {exp[tuple(bad)]!r}")
+
+
+def make_scene(oracle, n, n_levels, seed=None, index_base=0):
+    seed = oracle.SEED if seed is None else seed
+    lo = oracle.synth_level_offsets(n, n_levels)
+    par = oracle.synth_parents(lo, seed=seed, index_base=index_base)
+    trs = oracle.synth_trs(n, int(lo[1]), seed=seed, index_base=index_base)
+    bounds = oracle.synth_aabb(n, seed=seed, index_base=index_base)
+    return lo, par, trs, bounds
+
+
+def gpu_scene(ctx, lo, par, trs, bounds, n_frusta, **kw):
+    from yume_amd import Scene
+
+    n = trs.shape[1]
+    s = Scene(ctx, n, n_levels=len(lo) - 1, n_frusta=n_frusta, **kw)
+    s.upload_hierarchy(par, lo)
+    s.upload_trs(trs)
+    s.upload_aabb(np.ascontiguousarray(bounds[:, 0:3].T), np.ascontiguousarray(bounds[:, 3:6].T))
+    return s
+
+
+def check_frame(oracle, s, lo, par, trs, bounds, planes, threads=4, id_base=0):
+    planes = np.asarray(planes, np.float32).reshape(-1, 24)
+    exp_world = oracle.frame_trs(trs, par, lo, n_threads=threads)
+    vis, bnd = oracle.cull(exp_world, bounds, planes, n_threads=threads)
+    s.frame(planes)
+    got = s.world_soa()
+    assert_same_values(got, np.ascontiguousarray(exp_world["m"].T), "world")
+    counts, bcounts = s.counts()
+    n_bnd_total = 0
+    for f in range(planes.shape[0]):
+        exp_set = np.flatnonzero(vis[f]).astype(np.uint32) + np.uint32(id_base)
+        lst = s.draw_list(f)
+        assert counts[f] == exp_set.size == lst.size, f"frustum {f}: count {counts[f]} vs {exp_set.size}"
+        assert np.array_equal(np.sort(lst), exp_set), f"frustum {f}: visible set differs"
+        assert bcounts[f] == np.count_nonzero(bnd[f]), f"frustum {f}: boundary count"
+        n_bnd_total += int(bcounts[f])
+    return n_bnd_total
+
+
+# ---------------------------------------------------------------------------------------------- generator
+def test_device_generator_matches_oracle(ctx, oracle):
+    from yume_amd import Scene
+
+    n = 200_000
+    lo = oracle.synth_level_offsets(n, 8)
+    par = oracle.synth_parents(lo)
+    for base in (0, 5_000_000_000):
+        with Scene(ctx, n, n_levels=8, n_frusta=1) as s:
+            s.upload_hierarchy(par, lo)
+            s.fill_synthetic(index_base=base)
+            trs = s.download_trs()
+            mins, maxs = s.download_aabb()
+        exp = oracle.synth_trs(n, int(lo[1]), index_base=base)
+        diff = (trs.view(np.uint32) != exp.view(np.uint32)).sum(axis=1)
+        assert not diff.any(), f"planes differing (count per plane): {diff.tolist()}"
+        b = oracle.synth_aabb(n, index_base=base)
+        assert np.array_equal(mins.T, b[:, 0:3]) and np.array_equal(maxs.T, b[:, 3:6])
+
+
+# ------------------------------------------------------------------------------------------------ compose
+def test_compose_random(ctx, oracle):
+    from yume_amd import Scene
+
+    n = 100_000
+    trs = oracle.synth_trs(n, n // 2)
+    with Scene(ctx, n, n_frusta=0, bounds_kind=0) as s:
+        s.upload_flat()
+        s.upload_trs(trs)
+        got = s.compose()
+    exp = oracle.compose_batch(trs)["m"].T
+    assert_same_values(got, exp, "compose")
+
+
+def test_compose_edge_cases(ctx, oracle):
+    """Identity, zero scale, unnormalised and zero quaternions, signed zeros, overflow and non-finite inputs:
+    the closed form must fall back to the literal two-product path wherever the reference yields NaN."""
+    from yume_amd import Scene
+
+    inf, nan, big = np.inf, np.nan, 3e38
+    rows = [
+        [0, 0, 0, 0, 0, 0, 1, 1, 1, 1],
+        [1, 2, 3, 0, 0, 0, 0, 1, 1, 1],
+        [1, 2, 3, 0.5, 0.5, 0.5, 0.5, 0, 0, 0],
+        [-0.0, 0.0, -0.0, -0.0, 0.0, -0.0, 1, -1, 2, -3],
+        [1, 2, 3, 2, -3, 4, 5, 1, 1, 1],
+        [inf, 0, 0, 0, 0, 0, 1, 1, 1, 1],
+        [0, -inf, 0, 0, 0, 0, 1, 1, 1, 1],
+        [nan, 0, 0, 0, 0, 0, 1, 1, 1, 1],
+        [0, 0, 0, inf, 0, 0, 1, 1, 1, 1],
+        [0, 0, 0, 0, 0, 0, inf, 1, 1, 1],
+        [0, 0, 0, 0, nan, 0, 1, 1, 1, 1],
+        [0, 0, 0, 0, 0, 0, 1, inf, 1, 1],
+        [0, 0, 0, 0, 0.5, 0.5, 0, inf, 1, 1],
+        [0, 0, 0, 0, 0, 0, 1, 1, nan, 1],
+        [0, 0, 0, 1e20, 1e20, 0, 1, 1, 1, 1],
+        [0, 0, 0, 1e19, 1, 1, 1e19, 1, 1, 1],
+        [big, big, big, 0.1, 0.2, 0.3, 0.9, big, big, big],
+        [1, 1, 1, 0.1, 0.2, 0.3, 0.9, 1e-40, 1e-45, 1],
+        [1e-45, -1e-45, 0, 1e-30, 1e-30, 1e-30, 1e-30, 1, 1, 1],
+    ]
+    trs = np.ascontiguousarray(np.array(rows, np.float32).T)
+    n = trs.shape[1]
+    with Scene(ctx, n, n_frusta=0, bounds_kind=0) as s:
+        s.upload_flat()
+        s.upload_trs(trs)
+        got = s.compose()
+        s.frame(None)
+        world = s.world_soa()
+    exp = oracle.compose_batch(trs)
+    with np.errstate(all="ignore"):
+        assert_same_values(got, exp["m"].T, "compose edge")
+        expw = oracle.frame_trs(trs, np.full(n, 0xFFFFFFFF, np.uint32), np.array([0, n], np.uint32))
+        assert_same_values(world, expw["m"].T, "world edge")
+
+
+# ------------------------------------------------------------------------------------------ whole frames
+def test_cfg1_flat_10k(ctx, oracle):
+    """BASELINE configs[0]: 10k flat entities, TRS->world + frustum cull."""
+    lo, par, trs, bounds = make_scene(oracle, 10_000, 1)
+    with gpu_scene(ctx, lo, par, trs, bounds, 1) as s:
+        check_frame(oracle, s, lo, par, trs, bounds, oracle.main_camera_planes())
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 5000])
+def test_ragged_sizes_flat(ctx, oracle, n):
+    lo, par, trs, bounds = make_scene(oracle, n, 1)
+    with gpu_scene(ctx, lo, par, trs, bounds, 1) as s:
+        check_frame(oracle, s, lo, par, trs, bounds, oracle.main_camera_planes())
+
+
+@pytest.mark.parametrize("group", [0, 1, 2, 3, 4, 8])
+def test_tree_4096_all_groupings(ctx, oracle, group):
+    lo, par, trs, bounds = make_scene(oracle, 4096, 8)
+    with gpu_scene(ctx, lo, par, trs, bounds, 1) as s:
+        s.set_grouping(group)
+        check_frame(oracle, s, lo, par, trs, bounds, oracle.main_camera_planes())
+
+
+@pytest.mark.parametrize("group", [0, 1, 2, 4, 8])
+def test_cfg2_tree_1m(ctx, oracle, group):
+    """BASELINE configs[1]: 1M entities, random 8-level hierarchy, single camera frustum."""
+    lo, par, trs, bounds = make_scene(oracle, 1_000_000, 8)
+    with gpu_scene(ctx, lo, par, trs, bounds, 1) as s:
+        s.set_grouping(group)
+        check_frame(oracle, s, lo, par, trs, bounds, oracle.main_camera_planes())
+        # a second frame must give the same answer (counters reset, lists rewritten)
+        check_frame(oracle, s, lo, par, trs, bounds, oracle.main_camera_planes())
+
+
+def test_deep_and_uneven_hierarchy(ctx, oracle):
+    """12 levels with hand-made uneven level sizes (some levels smaller than their parent level), root != identity."""
+    sizes = [3, 50, 7, 900, 901, 20, 4000, 1, 300, 2000, 5, 1024]
+    lo = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    n = int(lo[-1])
+    par = oracle.synth_parents(lo)
+    trs = oracle.synth_trs(n, int(lo[1]))
+    bounds = oracle.synth_aabb(n)
+    root = oracle.identity68()
+    root["m"][0] = oracle.compose([3, -2, 1], [0.1, 0.2, 0.3, 0.9], [1.5, 0.5, 2])
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    for group in (0, 1, 3, 8):
+        with gpu_scene(ctx, lo, par, trs, bounds, 1) as s:
+            s.set_grouping(group)
+            s.set_root(root["m"][0])
+            exp = oracle.frame_trs(trs, par, lo, root=root.copy())
+            vis, _ = oracle.cull(exp, bounds, planes)
+            s.frame(planes)
+            assert_same_values(s.world_soa(), exp["m"].T, f"world g={group}")
+            assert np.array_equal(np.sort(s.draw_list(0)), np.flatnonzero(vis[0]).astype(np.uint32))
+
+
+def test_cfg3_five_frusta_1m(ctx, oracle):
+    """Small instance of configs[2]: main camera + 4 shadow cascades."""
+    lo, par, trs, bounds = make_scene(oracle, 1_000_000, 1)
+    planes = np.concatenate([oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()])
+    with gpu_scene(ctx, lo, par, trs, bounds, 5) as s:
+        check_frame(oracle, s, lo, par, trs, bounds, planes)
+
+
+def test_cfg3_full_16m(ctx, oracle):
+    """BASELINE configs[2] at full size: 16M flat entities, 5 frusta."""
+    n = 16 * 1024 * 1024
+    lo, par, trs, bounds = make_scene(oracle, n, 1)
+    planes = np.concatenate([oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()])
+    with gpu_scene(ctx, lo, par, trs, bounds, 5) as s:
+        nb = check_frame(oracle, s, lo, par, trs, bounds, planes, threads=16)
+    print("boundary cases at 16M x 5 frusta:", nb)
+
+
+def test_mesh_table_bounds(ctx, oracle):
+    """configs[4] flavour: instanced AABBs (mesh table + id), 4M flat instances, id_base offset."""
+    from yume_amd import Scene
+
+    n, nm, base = 4_000_000, 16, 1000
+    trs = oracle.synth_trs(n, n)
+    table = oracle.synth_mesh_table(nm)
+    ids = oracle.synth_mesh_ids(n, nm)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    with Scene(ctx, n, n_frusta=1, bounds_kind=2, max_meshes=nm, id_base=base) as s:
+        s.upload_flat()
+        s.upload_trs(trs)
+        s.upload_mesh_aabbs(table)
+        s.upload_mesh_ids(ids)
+        s.frame(planes)
+        exp = oracle.frame_trs(trs, np.full(n, 0xFFFFFFFF, np.uint32), np.array([0, n], np.uint32), n_threads=8)
+        vis, bnd = oracle.cull(exp, table, planes, mesh_id=ids, n_threads=8)
+        assert_same_values(s.world_soa(), exp["m"].T, "world")
+        assert np.array_equal(np.sort(s.draw_list(0)), np.flatnonzero(vis[0]).astype(np.uint32) + np.uint32(base))
+        assert s.counts()[1][0] == np.count_nonzero(bnd[0])
+        # device-side fill of the same scene gives the same inputs
+        s.fill_synthetic()
+        s.frame(planes)
+        assert np.array_equal(np.sort(s.draw_list(0)), np.flatnonzero(vis[0]).astype(np.uint32) + np.uint32(base))
+
+
+def test_boundary_cases_are_counted(ctx, oracle):
+    """Entities placed exactly on / within 1e-5 of a plane are reported in boundary_counts."""
+    from yume_amd import Scene
+
+    n = 1000
+    trs = np.zeros((10, n), np.float32)
+    trs[6] = 1
+    trs[7:10] = 1
+    trs[0] = np.linspace(-3, 3, n, dtype=np.float32)
+    trs[0, 10] = -1.0
+    trs[0, 11] = np.float32(-0.999995)
+    pl = np.array([[1, 0, 0, 0], [-1, 0, 0, 100], [0, 1, 0, 100], [0, -1, 0, 100], [0, 0, 1, 100], [0, 0, -1, 100]],
+                  np.float32).reshape(1, 24)
+    bounds = np.tile(np.array([-1, -1, -1, 1, 1, 1], np.float32), (n, 1))
+    lo = np.array([0, n], np.uint32)
+    par = np.full(n, 0xFFFFFFFF, np.uint32)
+    with gpu_scene(ctx, lo, par, trs, bounds, 1) as s:
+        nb = check_frame(oracle, s, lo, par, trs, bounds, pl)
+    assert nb >= 2
+
+
+def test_no_cull_and_empty_visibility(ctx, oracle):
+    lo, par, trs, bounds = make_scene(oracle, 30_000, 4)
+    far_away = np.array([[1, 0, 0, -1e6]] * 6, np.float32).reshape(1, 24)  # nothing satisfies x >= 1e6
+    from yume_amd import _lib
+
+    with gpu_scene(ctx, lo, par, trs, bounds, 1) as s:
+        s.frame(far_away)
+        assert s.counts()[0][0] == 0 and s.draw_list(0).size == 0
+        s.frame(None, flags=_lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_NO_CULL)
+        assert_same_values(s.world_soa(), oracle.frame_trs(trs, par, lo)["m"].T, "world")
+
+
+# ---------------------------------------------------------------------------------------- error behaviour
+def test_error_codes(ctx, oracle):
+    from yume_amd import Scene, _lib
+
+    E = _lib.YumeHipError
+    with pytest.raises(E) as e:
+        Scene(ctx, 0)
+    assert e.value.code == _lib.YH_ERR_BAD_ARG
+    with pytest.raises(E) as e:
+        Scene(ctx, 10, n_frusta=9)
+    assert e.value.code == _lib.YH_ERR_BAD_ARG
+    lo, par, trs, bounds = make_scene(oracle, 1000, 3)
+    with Scene(ctx, 1000, n_levels=3, n_frusta=1) as s:
+        with pytest.raises(E) as e:
+            s.frame(oracle.main_camera_planes())
+        assert e.value.code == _lib.YH_ERR_STATE  # hierarchy first
+        bad = par.copy()
+        bad[-1] = 0  # a level-2 entity pointing into level 0
+        with pytest.raises(E) as e:
+            s.upload_hierarchy(bad, lo)
+        assert e.value.code == _lib.YH_ERR_BAD_ARG
+        s.upload_hierarchy(par, lo)
+        with pytest.raises(E) as e:
+            s.upload_trs(trs, first=1)
+        assert e.value.code == _lib.YH_ERR_BAD_ARG  # range out of bounds
+        with pytest.raises(E) as e:
+            s.upload_local_aos68(np.zeros(4, oracle.T68))
+        assert e.value.code == _lib.YH_ERR_STATE
+        with pytest.raises(E) as e:
+            s.frame(np.zeros((2, 24), np.float32))
+        assert e.value.code == _lib.YH_ERR_BAD_ARG  # more frusta than draw lists
+        with pytest.raises(E) as e:
+            s.frame(oracle.main_camera_planes(), flags=0)
+        assert e.value.code == _lib.YH_ERR_UNSUPPORTED
+
+
+def test_draw_list_overflow_reports_required_size(ctx, oracle):
+    import ctypes as C
+
+    from yume_amd import _lib
+
+    lo, par, trs, bounds = make_scene(oracle, 50_000, 1)
+    with gpu_scene(ctx, lo, par, trs, bounds, 1, draw_capacity=100) as s:
+        s.frame(oracle.main_camera_planes())
+        counts, _ = s.counts()
+        exp = oracle.cull(oracle.frame_trs(trs, par, lo), bounds, oracle.main_camera_planes())[0][0].sum()
+        assert counts[0] == exp > 100  # the count keeps the required size
+        out = np.empty(100, np.uint32)
+        written = C.c_uint64()
+        rc = _lib.lib().yh_get_draw_list(s._h, 0, out.ctypes.data_as(C.c_void_p), 100, C.byref(written))
+        assert rc == _lib.YH_ERR_CAPACITY and written.value == exp
+    with gpu_scene(ctx, lo, par, trs, bounds, 1) as s:
+        s.frame(oracle.main_camera_planes())
+        out = np.empty(10, np.uint32)
+        written = C.c_uint64()
+        rc = _lib.lib().yh_get_draw_list(s._h, 0, out.ctypes.data_as(C.c_void_p), 10, C.byref(written))
+        assert rc == _lib.YH_ERR_CAPACITY and written.value == exp

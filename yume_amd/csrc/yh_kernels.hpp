@@ -329,10 +329,10 @@ __global__ __launch_bounds__(YH_BLOCK) void k_synth(float* __restrict__ trs, flo
     float q[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) q[c] = yh_synth_uniform(seed, 3u + (uint32_t)c, g, -1.0f, 1.0f);
-    const float len = __fsqrt_rn(q[3] * q[3] + q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    const float len = __builtin_sqrtf(q[3] * q[3] + q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);  // IEEE (see Makefile)
     if (len > 0.0f) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) q[c] = __fdiv_rn(q[c], len);
+        for (int c = 0; c < 4; ++c) q[c] = q[c] / len;
     } else {
         q[0] = q[1] = q[2] = 0.0f;
         q[3] = 1.0f;

@@ -71,6 +71,7 @@ struct yh_scene {
     uint64_t frames = 0;
     uint32_t last_launches = 0;
     bool kernel_timing = false;
+    bool frame_timed = false;
     std::vector<hipEvent_t> kev;  // YH_TIMING_RING pairs, lazily created
     std::vector<uint32_t> kev_group;
     uint32_t kev_used = 0;
@@ -529,15 +530,35 @@ extern "C" int yh_compose(yh_scene* s, float* const planes[16], uint64_t first, 
 }
 
 // ------------------------------------------------------------------------------------------------ frame
+// Dynamic LDS above 64 KiB (8 frusta x 8 KiB of staged indices + control words) needs the per-function opt-in.
+template <typename K>
+static void allow_big_lds(K kernel) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+}
+
+template <int G, int BOUNDS>
+static void launch_trs_g(dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a) {
+    static bool once = (allow_big_lds(k_frame_trs<G, BOUNDS>), true);
+    (void)once;
+    hipLaunchKernelGGL((k_frame_trs<G, BOUNDS>), grid, dim3(YH_BLOCK), lds, st, a);
+}
+
 template <int BOUNDS>
 static void launch_trs(int G, dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a) {
     switch (G) {
-        case 1: hipLaunchKernelGGL((k_frame_trs<1, BOUNDS>), grid, dim3(YH_BLOCK), lds, st, a); break;
-        case 2: hipLaunchKernelGGL((k_frame_trs<2, BOUNDS>), grid, dim3(YH_BLOCK), lds, st, a); break;
+        case 1: launch_trs_g<1, BOUNDS>(grid, lds, st, a); break;
+        case 2: launch_trs_g<2, BOUNDS>(grid, lds, st, a); break;
         case 3:
-        case 4: hipLaunchKernelGGL((k_frame_trs<4, BOUNDS>), grid, dim3(YH_BLOCK), lds, st, a); break;
-        default: hipLaunchKernelGGL((k_frame_trs<8, BOUNDS>), grid, dim3(YH_BLOCK), lds, st, a); break;
+        case 4: launch_trs_g<4, BOUNDS>(grid, lds, st, a); break;
+        default: launch_trs_g<8, BOUNDS>(grid, lds, st, a); break;
     }
+}
+
+template <int BOUNDS>
+static void launch_mat4(dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
+    static bool once = (allow_big_lds(k_level_mat4<BOUNDS>), true);
+    (void)once;
+    hipLaunchKernelGGL((k_level_mat4<BOUNDS>), grid, dim3(YH_BLOCK), lds, st, a, root_dirty);
 }
 
 static int ensure_kev(yh_scene* s) {
@@ -587,7 +608,7 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     const int bounds = cull ? (int)s->desc.bounds_kind : 0;
     const size_t lds = (32 + (size_t)a.n_frusta * YH_TILE) * sizeof(uint32_t);
 
-    HIP_TRY(ctx, hipEventRecord(s->ev0, st));
+    if (s->kernel_timing) HIP_TRY(ctx, hipEventRecord(s->ev0, st));
     HIP_TRY(ctx, hipMemsetAsync(s->counts, 0, 2 * YH_MAX_FRUSTA * 4, st));
     uint32_t launches = 0;
     if (s->kernel_timing)
@@ -636,9 +657,9 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
             a.has_base = k > 0;
             const dim3 grid(cdiv((uint64_t)a.end - a.begin, YH_TILE));
             if (int rc = time_begin(k)) return rc;
-            if (bounds == 0) hipLaunchKernelGGL((k_level_mat4<0>), grid, dim3(YH_BLOCK), lds, st, a, s->root_dirty);
-            else if (bounds == 1) hipLaunchKernelGGL((k_level_mat4<1>), grid, dim3(YH_BLOCK), lds, st, a, s->root_dirty);
-            else hipLaunchKernelGGL((k_level_mat4<2>), grid, dim3(YH_BLOCK), lds, st, a, s->root_dirty);
+            if (bounds == 0) launch_mat4<0>(grid, lds, st, a, s->root_dirty);
+            else if (bounds == 1) launch_mat4<1>(grid, lds, st, a, s->root_dirty);
+            else launch_mat4<2>(grid, lds, st, a, s->root_dirty);
             HIP_TRY(ctx, hipGetLastError());
             if (int rc = time_end()) return rc;
             ++launches;
@@ -651,7 +672,8 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     }
     s->root_dirty = 0;  // the world sweep clears the root's flag too
     HIP_TRY(ctx, hipMemcpyAsync(s->h_counts, s->counts, 2 * YH_MAX_FRUSTA * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipEventRecord(s->ev1, st));
+    if (s->kernel_timing) HIP_TRY(ctx, hipEventRecord(s->ev1, st));
+    s->frame_timed = s->kernel_timing;
     s->frame_pending = true;
     s->last_n_frusta = a.n_frusta;
     s->last_launches = launches;
@@ -697,7 +719,7 @@ extern "C" int yh_timings(yh_scene* s, yh_timing* out) {
     out->n_groups = (uint32_t)s->groups.size();
     if (s->frames == 0) return YH_OK;
     if (int rc = sync_scene(s)) return rc;
-    HIP_TRY(s->ctx, hipEventElapsedTime(&out->last_frame_ms, s->ev0, s->ev1));
+    if (s->frame_timed) HIP_TRY(s->ctx, hipEventElapsedTime(&out->last_frame_ms, s->ev0, s->ev1));
     // per-launch events (when enabled): mean duration of the slowest group since the last call
     if (s->kernel_timing && s->kev_used) {
         double sum[YH_MAX_LEVELS] = {0};
