@@ -70,7 +70,7 @@ typedef enum yh_bounds_kind {
 } yh_bounds_kind;
 
 typedef struct yh_scene_desc {
-    uint64_t n_entities;      /* <= 2^32 - 2 */
+    uint64_t n_entities;      /* 1 .. 2^30 (kernels address planes with 32-bit byte offsets) */
     uint32_t n_levels;        /* hierarchy depth, 1 = flat; <= YH_MAX_LEVELS */
     uint32_t n_frusta;        /* draw lists kept per frame; <= YH_MAX_FRUSTA */
     uint32_t local_kind;      /* yh_local_kind  */

@@ -75,7 +75,7 @@ def test_dirty_frames_match_reference_system(ctx, oracle):
                 assert_same_values(gl["m"], local["m"], f"{tag}: local")
             assert not gw["dirty"].any() and not gl["dirty"].any(), tag
             vis, bnd = oracle.cull(world, bounds, planes)
-            assert np.array_equal(np.sort(s.draw_list(0)), np.flatnonzero(vis[0]).astype(np.uint32)), tag
+            assert np.array_equal(s.draw_list(0), np.flatnonzero(vis[0]).astype(np.uint32)), tag
             assert s.counts()[1][0] == np.count_nonzero(bnd[0])
 
         step("frame 0 (everything dirty)")

@@ -59,7 +59,7 @@ def check_frame(oracle, s, lo, par, trs, bounds, planes, threads=4, id_base=0):
         exp_set = np.flatnonzero(vis[f]).astype(np.uint32) + np.uint32(id_base)
         lst = s.draw_list(f)
         assert counts[f] == exp_set.size == lst.size, f"frustum {f}: count {counts[f]} vs {exp_set.size}"
-        assert np.array_equal(np.sort(lst), exp_set), f"frustum {f}: visible set differs"
+        assert np.array_equal(lst, exp_set), f"frustum {f}: draw list differs (must be the visible set in ascending order)"
         assert bcounts[f] == np.count_nonzero(bnd[f]), f"frustum {f}: boundary count"
         n_bnd_total += int(bcounts[f])
     return n_bnd_total
@@ -194,7 +194,7 @@ def test_deep_and_uneven_hierarchy(ctx, oracle):
             vis, _ = oracle.cull(exp, bounds, planes)
             s.frame(planes)
             assert_same_values(s.world_soa(), exp["m"].T, f"world g={group}")
-            assert np.array_equal(np.sort(s.draw_list(0)), np.flatnonzero(vis[0]).astype(np.uint32))
+            assert np.array_equal(s.draw_list(0), np.flatnonzero(vis[0]).astype(np.uint32))
 
 
 def test_cfg3_five_frusta_1m(ctx, oracle):
@@ -233,12 +233,12 @@ def test_mesh_table_bounds(ctx, oracle):
         exp = oracle.frame_trs(trs, np.full(n, 0xFFFFFFFF, np.uint32), np.array([0, n], np.uint32), n_threads=8)
         vis, bnd = oracle.cull(exp, table, planes, mesh_id=ids, n_threads=8)
         assert_same_values(s.world_soa(), exp["m"].T, "world")
-        assert np.array_equal(np.sort(s.draw_list(0)), np.flatnonzero(vis[0]).astype(np.uint32) + np.uint32(base))
+        assert np.array_equal(s.draw_list(0), np.flatnonzero(vis[0]).astype(np.uint32) + np.uint32(base))
         assert s.counts()[1][0] == np.count_nonzero(bnd[0])
         # device-side fill of the same scene gives the same inputs
         s.fill_synthetic()
         s.frame(planes)
-        assert np.array_equal(np.sort(s.draw_list(0)), np.flatnonzero(vis[0]).astype(np.uint32) + np.uint32(base))
+        assert np.array_equal(s.draw_list(0), np.flatnonzero(vis[0]).astype(np.uint32) + np.uint32(base))
 
 
 def test_boundary_cases_are_counted(ctx, oracle):

@@ -1,112 +1,137 @@
 // yh_kernels.hpp — gfx950 kernels of the transform-and-visibility path.
 //
-// Data layout in HBM (per scene): every per-entity quantity is an f32/u32 SoA plane of `stride`
-// elements (stride = n_entities rounded up to 64, so each plane starts 256-B aligned):
-//   trs     10 planes  tx,ty,tz,qx,qy,qz,qw,sx,sy,sz        (Mat4.compose arguments, math3d.zig:816)
-//   lmat    16 planes  local Mat4 values[p]                 (imported flecs LocalTransform column)
-//   world   16 planes  world Mat4 values[p]                 (WorldTransform.matrix)
-//   parent  u32        slot of the parent (previous level)  (ChildOf pair, ecs.zig:470-477)
-//   bounds   6 planes  min.xyz,max.xyz  or  u32 mesh id + table (meshes.zig:72-95)
+// Data layout in HBM (per scene): "SoA in wave-sized chunks".  Entities are cut into chunks of 64 (one
+// wavefront); an array with NP f32 planes stores chunk c as NP consecutive 256-byte rows, row q holding
+// plane q of the chunk's 64 entities:
+//       byte offset of (entity e, plane q) = (e >> 6) * NP * 256  +  q * 256  +  (e & 63) * 4
+// A wave reading plane q of its own chunk issues one fully coalesced 256-B access, all NP accesses of an
+// entity share ONE per-lane address (the plane is the instruction's immediate offset, q*256 < 4096), and a
+// wave's whole working set is a handful of contiguous 1.5-4 KiB blocks (DRAM-page and TLB friendly) instead
+// of 48 streams hundreds of MB apart.
+//   trs     NP=10  tx,ty,tz,qx,qy,qz,qw,sx,sy,sz          (Mat4.compose arguments, math3d.zig:816)
+//   lmat    NP=16  local Mat4 values[p]                   (imported flecs LocalTransform column)
+//   world   NP=16  world Mat4 values[p]                   (WorldTransform.matrix)
+//   bounds  NP=6   min.xyz,max.xyz   or  u32 mesh id per entity + table (meshes.zig:72-95)
+//   parent  u32    slot of the parent (previous level)    (ChildOf pair, ecs.zig:470-477)
 //   ldirty/wdirty  u8  LocalTransform.dirty / WorldTransform.dirty (transform.zig:12,66)
 // Entities are stored level-major (depth-sorted), siblings contiguous and sorted by parent, so a wave's
-// 64 consecutive children read a short contiguous run of parents.
+// 64 consecutive children gather from a short contiguous run of parent chunks.
 //
-// All kernels are HBM-bound streaming kernels: one entity per lane, 4-byte coalesced plane accesses
-// (256 B per wave-instruction), no MFMA.
+// All kernels are HBM-bound streaming kernels: one entity per lane, no MFMA.
 #pragma once
 #include "yh_math.hpp"
 
 #define YH_K_MAX_FRUSTA 8
 #define YH_BLOCK 256
-#define YH_ITERS 8
-#define YH_TILE (YH_BLOCK * YH_ITERS) /* entities per workgroup = per global draw-list reservation */
-#define YH_MAX_GROUP 8                /* levels one launch may span */
+#define YH_MAX_ITERS 8 /* a workgroup handles iters x 256 consecutive entities */
+#define YH_MAX_GROUP 8 /* levels one launch may span */
+#define YH_CHUNK 64
 
 struct FrameArgs {
     const float* trs;
     const float* lmat;
     const uint32_t* parent;
-    const float* bounds;      // per-entity planes, or mesh table (n_meshes x 6)
+    const float* bounds;      // chunked planes, or mesh table (n_meshes x 6)
     const uint32_t* mesh_id;  // mesh-table mode
     float* world;
     uint8_t* ldirty;
     uint8_t* wdirty;
-    uint32_t* counts;   // [YH_K_MAX_FRUSTA] visible, then [YH_K_MAX_FRUSTA] boundary
-    uint32_t* draw[YH_K_MAX_FRUSTA];
-    uint64_t stride;
-    uint64_t draw_cap;
-    uint32_t begin, end;                 // entity range of this launch (levels lo..hi)
-    uint32_t lvl_begin[YH_MAX_GROUP];    // first slot of levels lo+1, lo+2, ... (0xFFFFFFFF when absent)
-    uint32_t has_base;                   // lo > 0: the group's top level has stored parents
+    uint32_t* bcount;    // [YH_K_MAX_FRUSTA] boundary-case counters of this frame
+    uint64_t* vismask;   // [frustum][n_chunks] one visibility bit per entity (wave ballots)
+    uint32_t n_chunks;
+    uint32_t begin, end;               // entity range of this launch (levels lo..hi)
+    uint32_t lvl_begin[YH_MAX_GROUP];  // first slot of levels lo+1, lo+2, ... (0xFFFFFFFF when absent)
     uint32_t n_frusta;
     uint32_t id_base;
     uint32_t n_meshes;
+    uint32_t iters;  // 256-entity slices per workgroup (1..YH_MAX_ITERS)
     float root[16];
     float planes[YH_K_MAX_FRUSTA * 24];
 };
+
+// ---- chunked-plane addressing -------------------------------------------------------------------------
+template <int NP>
+__host__ __device__ __forceinline__ uint64_t eoff(uint32_t e) {
+    return (uint64_t)(e >> 6) * (uint64_t)(NP * 256) + (uint64_t)((e & 63u) << 2);
+}
+__device__ __forceinline__ float lde(const float* __restrict__ base, uint64_t off, int q) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off + q * 256);
+}
+__device__ __forceinline__ void ste(float* __restrict__ base, uint64_t off, int q, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off + q * 256) = v;
+}
+template <int NP>
+__device__ __forceinline__ void load_row(const float* __restrict__ base, uint32_t e, float (&out)[NP]) {
+    const uint64_t off = eoff<NP>(e);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) out[q] = lde(base, off, q);
+}
+template <int NP>
+__device__ __forceinline__ void store_row(float* __restrict__ base, uint32_t e, const float (&v)[NP]) {
+    const uint64_t off = eoff<NP>(e);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) ste(base, off, q, v[q]);
+}
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// LDS layout of the frame kernels: 32 control words, then n_frusta x YH_TILE staged draw indices.
-//   [0..7] visible count per frustum   [8..15] boundary count   [16..23] global base of this tile
-__device__ __forceinline__ void stage_visible(uint32_t* smem, uint32_t n_frusta, uint32_t vmask, uint32_t bmask,
-                                              uint32_t id) {
+// ---- stage 3 back end, part 1: wavefront ballots ---------------------------------------------------------
+// Every wave owns exactly one 64-entity chunk (launches are chunk-aligned), so its ballot IS the chunk's
+// visibility word.  Lane 0 stores it: no LDS, no barrier, no atomic on a shared address (tile counters fed by
+// one atomic per wave cost 10-70 % of the launch when measured) and nothing to zero between frames.  A chunk
+// that straddles two launches is stored by the earlier one (upper lanes zero) and OR-ed into by the first wave
+// of the later one; launches of a frame run in stream order, so the plain read-modify-write is race-free.
+__device__ __forceinline__ void publish_visible(const FrameArgs& a, uint32_t chunk, bool merge_with_previous_launch,
+                                                uint32_t vmask, uint32_t bmask) {
     const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t f = 0; f < n_frusta; ++f) {
-        const bool v = (vmask >> f) & 1u;
-        const uint64_t m = __ballot(v);
-        if (m) {  // wave-uniform
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&smem[f], (uint32_t)__popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (v) smem[32 + f * YH_TILE + base + lane_rank(m)] = id;
-        }
-        const uint64_t bm = __ballot((bmask >> f) & 1u);
-        if (bm && lane == 0) atomicAdd(&smem[8 + f], (uint32_t)__popcll(bm));
-    }
-}
-
-// One global reservation per tile per frustum, then a coalesced copy of the staged indices.
-__device__ __forceinline__ void flush_visible(uint32_t* smem, const FrameArgs& a) {
-    __syncthreads();
-    const uint32_t tid = threadIdx.x;
-    if (tid < a.n_frusta) {
-        const uint32_t c = smem[tid];
-        smem[16 + tid] = c ? atomicAdd(&a.counts[tid], c) : 0u;
-        const uint32_t bc = smem[8 + tid];
-        if (bc) atomicAdd(&a.counts[YH_K_MAX_FRUSTA + tid], bc);
-    }
-    __syncthreads();
     for (uint32_t f = 0; f < a.n_frusta; ++f) {
-        const uint32_t c = smem[f];
-        const uint64_t g = smem[16 + f];
-        uint32_t* __restrict__ out = a.draw[f];
-        for (uint32_t i = tid; i < c; i += YH_BLOCK) {
-            if (g + i < a.draw_cap) out[g + i] = smem[32 + f * YH_TILE + i];
+        const uint64_t m = __ballot((vmask >> f) & 1u);
+        const uint64_t bm = __ballot((bmask >> f) & 1u);
+        if (lane == 0) {
+            uint64_t* w = &a.vismask[(uint64_t)f * a.n_chunks + chunk];
+            *w = merge_with_previous_launch ? (*w | m) : m;
+            if (bm) atomicAdd(&a.bcount[f], (uint32_t)__popcll(bm));
         }
     }
 }
 
 template <int BOUNDS>
-__device__ __forceinline__ void cull_entity(const FrameArgs& a, const M4& w, uint32_t e, uint32_t& vmask,
-                                            uint32_t& bmask) {
+__device__ __forceinline__ void cull_entity(const FrameArgs& a, const M4& w, const float* b6, uint32_t mesh,
+                                            uint32_t& vmask, uint32_t& bmask) {
     float b[6];
     if (BOUNDS == 1) {
 #pragma unroll
-        for (int p = 0; p < 6; ++p) b[p] = a.bounds[(uint64_t)p * a.stride + e];
+        for (int p = 0; p < 6; ++p) b[p] = b6[p];
     } else {
-        const uint32_t m = a.mesh_id[e];
 #pragma unroll
-        for (int p = 0; p < 6; ++p) b[p] = a.bounds[(uint64_t)m * 6 + p];
+        for (int p = 0; p < 6; ++p) b[p] = a.bounds[mesh * 6u + p];
     }
     const CullBox box = cull_box(w, b[0], b[1], b[2], b[3], b[4], b[5]);
+#pragma unroll 1
     for (uint32_t f = 0; f < a.n_frusta; ++f) {
         const uint32_t r = cull_frustum(w, box, &a.planes[f * 24]);
         vmask |= (r & 1u) << f;
         bmask |= (r >> 1) << f;
     }
+}
+
+// Per-entity streamed inputs of the TRS frame kernel (stage-1 operands, bounds, parent slot).
+template <int BOUNDS>
+struct TrsInputs {
+    float t[10];
+    float b[6];
+    uint32_t pidx;
+    uint32_t mesh;
+};
+
+template <int BOUNDS, bool NEED_PARENT>
+__device__ __forceinline__ void load_inputs(const FrameArgs& a, uint32_t e, TrsInputs<BOUNDS>& in) {
+    load_row<10>(a.trs, e, in.t);
+    if (BOUNDS == 1) load_row<6>(a.bounds, e, in.b);
+    in.mesh = (BOUNDS == 2) ? a.mesh_id[e] : 0u;
+    in.pidx = NEED_PARENT ? a.parent[e] : 0u;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -119,62 +144,82 @@ __device__ __forceinline__ void cull_entity(const FrameArgs& a, const M4& w, uin
 // same order as level-by-level propagation, so the values are identical; the recomputation trades a few
 // hundred VALU ops (free under the HBM bound) for G-1 fewer dependent launches.
 //   stage 1: Mat4.compose per chain element   stage 2: Mat4.mul chain   stage 3: cull + compaction.
-// BOUNDS: 0 none, 1 per-entity planes, 2 mesh table.
-template <int G, int BOUNDS>
+// A workgroup walks `iters` slices of 256 consecutive entities; with PREFETCH the streamed inputs of slice
+// i+1 are requested before slice i is computed (register double buffer), so the parent gather of a slice
+// never waits for its own index load.  BOUNDS: 0 none, 1 per-entity planes, 2 mesh table.  HAS_BASE: the
+// group's first level is > 0 (its entities have stored parents).
+template <int G, int BOUNDS, bool HAS_BASE, bool PREFETCH>
 __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs(const FrameArgs a) {
-    extern __shared__ uint32_t smem[];
     const uint32_t tid = threadIdx.x;
-    if (tid < 32) smem[tid] = 0;
-    __syncthreads();
-    const uint64_t tile0 = (uint64_t)a.begin + (uint64_t)blockIdx.x * YH_TILE;
-    const uint64_t S = a.stride;
+    const uint32_t tile = a.iters * YH_BLOCK;
+    // chunk-aligned mapping: every wave covers exactly one 64-entity chunk of the arrays
+    const uint64_t tile0 = (uint64_t)(a.begin & ~63u) + (uint64_t)blockIdx.x * tile;
+    const uint32_t last = a.end - 1;
+    constexpr bool NEED_PARENT = HAS_BASE || (G > 1);
+    // lanes outside [begin, end) redo a valid entity of the launch and store nothing
+    auto clamp_e = [&](uint64_t e64) -> uint32_t { return e64 < a.begin ? a.begin : (e64 < a.end ? (uint32_t)e64 : last); };
 
+    TrsInputs<BOUNDS> cur;
+    if (PREFETCH) load_inputs<BOUNDS, NEED_PARENT>(a, clamp_e(tile0 + tid), cur);
 #pragma unroll 1
-    for (int it = 0; it < YH_ITERS; ++it) {
+    for (uint32_t it = 0; it < a.iters; ++it) {
         const uint64_t e64 = tile0 + (uint64_t)it * YH_BLOCK + tid;
-        const bool valid = e64 < a.end;
-        const uint32_t e = (uint32_t)e64;
-        uint32_t vmask = 0, bmask = 0;
-        if (valid) {
-            // depth of e inside the group
-            int d = 0;
-#pragma unroll
-            for (int j = 0; j < G - 1; ++j) d += (e >= a.lvl_begin[j]) ? 1 : 0;
-            // ancestor chain: chain[0] = e, chain[j] = parent of chain[j-1]
-            uint32_t chain[G];
-            uint32_t p = e;
-#pragma unroll
-            for (int j = 0; j < G; ++j) {
-                chain[j] = p;
-                if (j < d) p = a.parent[p];
-            }
-            M4 w;
-            if (a.has_base) {
-                const uint32_t bp = a.parent[p];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) w.v[q] = a.world[(uint64_t)q * S + bp];
-            } else {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) w.v[q] = a.root[q];
-            }
-#pragma unroll
-            for (int j = G - 1; j >= 0; --j) {
-                if (j <= d) {
-                    const uint32_t c = chain[j];
-                    float t[10];
-#pragma unroll
-                    for (int q = 0; q < 10; ++q) t[q] = a.trs[(uint64_t)q * S + c];
-                    const M4 l = m4_compose(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
-                    w = m4_mul(w, l);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) a.world[(uint64_t)q * S + e] = w.v[q];
-            if (BOUNDS != 0) cull_entity<BOUNDS>(a, w, e, vmask, bmask);
+        if (e64 - tid + (tid & ~63u) >= a.end) break;  // this wave's chunk starts past the end (wave-uniform)
+        const bool valid = e64 >= a.begin && e64 < a.end;
+        const uint32_t e = clamp_e(e64);
+        TrsInputs<BOUNDS> nxt;
+        if (PREFETCH) {
+            nxt = cur;
+            if (it + 1 < a.iters) load_inputs<BOUNDS, NEED_PARENT>(a, clamp_e(e64 + YH_BLOCK), nxt);
+        } else {
+            load_inputs<BOUNDS, NEED_PARENT>(a, e, cur);
         }
-        if (BOUNDS != 0) stage_visible(smem, a.n_frusta, vmask, bmask, e + a.id_base);
+        // depth of e inside the group, and its ancestor chain: chain[0] = e, chain[j] = parent of chain[j-1]
+        int d = 0;
+#pragma unroll
+        for (int j = 0; j < G - 1; ++j) d += (e >= a.lvl_begin[j]) ? 1 : 0;
+        uint32_t chain[G];
+        uint32_t p = e;
+        uint32_t pp = cur.pidx;  // parent slot of p (meaningful while p has a stored parent)
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            chain[j] = p;
+            if (j < d) {
+                p = pp;
+                if (HAS_BASE || j + 1 < d) pp = a.parent[p];
+            }
+        }
+        M4 w;
+        if (HAS_BASE) {
+            load_row<16>(a.world, pp, w.v);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) w.v[q] = a.root[q];
+        }
+#pragma unroll
+        for (int j = G - 1; j >= 1; --j) {
+            if (j <= d) {
+                float t[10];
+                load_row<10>(a.trs, chain[j], t);
+                const M4 l = m4_compose(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
+                w = m4_mul(w, l);
+            }
+        }
+        {
+            const M4 l = m4_compose(cur.t[0], cur.t[1], cur.t[2], cur.t[3], cur.t[4], cur.t[5], cur.t[6], cur.t[7],
+                                    cur.t[8], cur.t[9]);
+            w = m4_mul(w, l);
+        }
+        if (valid) store_row<16>(a.world, e, w.v);
+        if (BOUNDS != 0) {
+            uint32_t vmask = 0, bmask = 0;
+            cull_entity<BOUNDS>(a, w, cur.b, cur.mesh, vmask, bmask);
+            if (!valid) vmask = bmask = 0;
+            const uint64_t c0 = e64 - (tid & 63u);  // first entity of this wave's chunk
+            publish_visible(a, (uint32_t)(e64 >> 6), c0 < a.begin, vmask, bmask);
+        }
+        if (PREFETCH) cur = nxt;
     }
-    if (BOUNDS != 0) flush_visible(smem, a);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -182,25 +227,23 @@ __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs(const FrameArgs a) {
 // TransformSyncSystem.zig:60-73, one level per launch (the parent's dirty flag must already be this
 // frame's), followed by the culling stage.  The dirty reset of PostTransformSystem.zig:31-35 is done by
 // k_clear_dirty after the last level.
-template <int BOUNDS>
+template <int BOUNDS, bool HAS_BASE>
 __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, const uint32_t root_dirty) {
-    extern __shared__ uint32_t smem[];
     const uint32_t tid = threadIdx.x;
-    if (tid < 32) smem[tid] = 0;
-    __syncthreads();
-    const uint64_t tile0 = (uint64_t)a.begin + (uint64_t)blockIdx.x * YH_TILE;
-    const uint64_t S = a.stride;
+    const uint32_t tile = a.iters * YH_BLOCK;
+    const uint64_t tile0 = (uint64_t)(a.begin & ~63u) + (uint64_t)blockIdx.x * tile;
 
 #pragma unroll 1
-    for (int it = 0; it < YH_ITERS; ++it) {
+    for (uint32_t it = 0; it < a.iters; ++it) {
         const uint64_t e64 = tile0 + (uint64_t)it * YH_BLOCK + tid;
-        const bool valid = e64 < a.end;
+        if (e64 - tid + (tid & ~63u) >= a.end) break;  // wave-uniform
+        const bool valid = e64 >= a.begin && e64 < a.end;
         const uint32_t e = (uint32_t)e64;
         uint32_t vmask = 0, bmask = 0;
         if (valid) {
             uint32_t bp = 0;
             bool pd;
-            if (a.has_base) {
+            if (HAS_BASE) {
                 bp = a.parent[e];
                 pd = a.wdirty[bp] != 0;
             } else {
@@ -211,9 +254,8 @@ __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, cons
             M4 w;
             if (pd || ld || wd) {  // :62-64
                 M4 pm;
-                if (a.has_base) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) pm.v[q] = a.world[(uint64_t)q * S + bp];
+                if (HAS_BASE) {
+                    load_row<16>(a.world, bp, pm.v);
                 } else {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) pm.v[q] = a.root[q];
@@ -221,29 +263,129 @@ __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, cons
                 a.wdirty[e] = 1;  // :65
                 if (ld || pd) {   // :67-68
                     M4 l;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) l.v[q] = a.lmat[(uint64_t)q * S + e];
+                    load_row<16>(a.lmat, e, l.v);
                     w = m4_mul(pm, l);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) a.world[(uint64_t)q * S + e] = w.v[q];
+                    store_row<16>(a.world, e, w.v);
                 } else {  // :69-72 world-edited entity: re-derive the local matrix
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) w.v[q] = a.world[(uint64_t)q * S + e];
+                    load_row<16>(a.world, e, w.v);
                     M4 inv;
                     if (!m4_inverse(pm, inv)) inv = m4_identity();
                     const M4 l = m4_mul(inv, w);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) ((float*)a.lmat)[(uint64_t)q * S + e] = l.v[q];
+                    store_row<16>(const_cast<float*>(a.lmat), e, l.v);
                 }
             } else {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) w.v[q] = a.world[(uint64_t)q * S + e];
+                load_row<16>(a.world, e, w.v);
             }
-            if (BOUNDS != 0) cull_entity<BOUNDS>(a, w, e, vmask, bmask);
+            if (BOUNDS != 0) {
+                float b[6] = {0, 0, 0, 0, 0, 0};
+                uint32_t mesh = 0;
+                if (BOUNDS == 1) load_row<6>(a.bounds, e, b);
+                else mesh = a.mesh_id[e];
+                cull_entity<BOUNDS>(a, w, b, mesh, vmask, bmask);
+            }
         }
-        if (BOUNDS != 0) stage_visible(smem, a.n_frusta, vmask, bmask, e + a.id_base);
+        if (BOUNDS != 0) {
+            const uint64_t c0 = e64 - (tid & 63u);
+            publish_visible(a, (uint32_t)(e64 >> 6), c0 < a.begin, vmask, bmask);
+        }
     }
-    if (BOUNDS != 0) flush_visible(smem, a);
+}
+
+// ---- stage 3 back end, part 2: prefix sums + expansion into ordered draw lists -----------------------------
+// An expand tile is 256 visibility words (16384 entities).  k_count reduces every tile to its visible count;
+// k_expand gives one workgroup to each (tile, frustum): its base is the sum of the tile counts before it (read
+// redundantly: <= a few thousand L2-resident words, cheaper than a dependent scan launch), the 256 words are
+// prefix-summed through LDS and the 4 waves expand them round-robin, one word per step: lane l emits entity
+// chunk*64+l at rank mbcnt(word).  Ascending entity order, coalesced stores, no atomics.  Scenes of at most
+// YH_SELF_COUNT_TILES tiles skip k_count: every workgroup popcounts the words before its tile itself.
+#define YH_EXPAND_WORDS 256
+#define YH_SELF_COUNT_TILES 64
+
+struct ExpandArgs {
+    const uint64_t* vismask;
+    uint32_t* tilecnt;      // [frustum][n_tiles]
+    uint32_t* counts;       // device totals [frustum] (input of the RCCL all-gather)
+    uint32_t* bcount_cur;   // boundary counters accumulated by this frame's launches
+    uint32_t* bcount_next;  // the other parity: zeroed here for the next frame
+    uint32_t* host_counts;  // host-mapped: [frustum] totals, [8 + frustum] boundary counts
+    uint32_t* draw[YH_K_MAX_FRUSTA];
+    uint64_t draw_cap;
+    uint32_t n_chunks, n_tiles, id_base, self_count;
+};
+
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* s_red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const uint32_t r = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(YH_BLOCK) void k_count(const ExpandArgs x) {
+    __shared__ uint32_t s_red[4];
+    const uint32_t t = blockIdx.x, f = blockIdx.y;
+    const uint32_t c = t * YH_EXPAND_WORDS + threadIdx.x;
+    const uint64_t m = c < x.n_chunks ? x.vismask[(uint64_t)f * x.n_chunks + c] : 0ull;
+    const uint32_t total = block_sum_256((uint32_t)__popcll(m), s_red);
+    if (threadIdx.x == 0) x.tilecnt[f * x.n_tiles + t] = total;
+}
+
+__global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) {
+    __shared__ uint32_t s_red[4];
+    __shared__ uint32_t s_off[YH_BLOCK];
+    __shared__ uint64_t s_mask[YH_BLOCK];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t t = blockIdx.x, f = blockIdx.y;
+    const uint64_t* __restrict__ masks = x.vismask + (uint64_t)f * x.n_chunks;
+    const uint32_t c0 = t * YH_EXPAND_WORDS;
+    const uint32_t c = c0 + tid;
+    const uint64_t m = c < x.n_chunks ? masks[c] : 0ull;
+    const uint32_t pc = (uint32_t)__popcll(m);
+    // base = visible entities in the tiles before this one
+    uint32_t part = 0;
+    if (x.self_count) {
+        for (uint32_t i = tid; i < c0; i += YH_BLOCK) part += (uint32_t)__popcll(masks[i]);
+    } else {
+        const uint32_t* __restrict__ cnt = x.tilecnt + (uint64_t)f * x.n_tiles;
+        for (uint32_t i = tid; i < t; i += YH_BLOCK) part += cnt[i];
+    }
+    const uint32_t base = block_sum_256(part, s_red);
+    // exclusive scan of the 256 popcounts
+    uint32_t inc = pc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o);
+        if ((int)lane >= o) inc += v;
+    }
+    if (lane == 63) s_red[wv] = inc;
+    s_mask[tid] = m;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < wv; ++w) wbase += s_red[w];
+    s_off[tid] = wbase + inc - pc;
+    const uint32_t own = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    if (tid == 0) {
+        if (t == 0) x.bcount_next[f] = 0;
+        if (t + 1 == x.n_tiles) {  // totals of this frustum, to the device (all-gather) and straight to the host
+            x.counts[f] = base + own;
+            x.host_counts[f] = base + own;
+            x.host_counts[YH_K_MAX_FRUSTA + f] = x.bcount_cur[f];
+        }
+    }
+    if (own == 0) return;
+    uint32_t* __restrict__ out = x.draw[f];
+    const uint32_t n_words = min((uint32_t)YH_EXPAND_WORDS, x.n_chunks - c0);
+#pragma unroll 4
+    for (uint32_t k = wv; k < n_words; k += 4) {
+        const uint64_t mk = s_mask[k];  // wave-uniform
+        if (mk) {
+            const uint64_t pos = (uint64_t)base + s_off[k] + lane_rank(mk);
+            if (((mk >> lane) & 1ull) && pos < x.draw_cap) out[pos] = ((c0 + k) << 6) + lane + x.id_base;
+        }
+    }
 }
 
 // PostWorldTransform + PostLocalTransform (PostTransformSystem.zig:31-35): both dirty planes to 0.
@@ -261,27 +403,48 @@ __global__ __launch_bounds__(YH_BLOCK) void k_fill_u8(uint8_t* __restrict__ p, u
     if (i < count) p[first + i] = v;
 }
 
-// Stage 1 alone: batched Mat4.compose (math3d.zig:816-822) into 16 planes.
-__global__ __launch_bounds__(YH_BLOCK) void k_compose(const float* __restrict__ trs, float* __restrict__ out, uint64_t S,
-                                                      uint64_t out_stride, uint64_t first, uint64_t count) {
+// Fill plane q of a chunked array with a constant (scene creation: world = IDENTITY).
+__global__ __launch_bounds__(YH_BLOCK) void k_fill_plane(float* __restrict__ arr, uint32_t np, uint32_t q, float v,
+                                                         uint64_t n) {
+    const uint64_t e = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;
+    if (e < n) arr[(e >> 6) * (np * 64ull) + q * 64ull + (e & 63)] = v;
+}
+
+// Host planes <-> chunked arrays (uploads / downloads; not on the per-frame path).
+__global__ __launch_bounds__(YH_BLOCK) void k_scatter_plane(const float* __restrict__ src, float* __restrict__ arr,
+                                                            uint32_t np, uint32_t q, uint64_t first, uint64_t count) {
     const uint64_t i = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;
     if (i >= count) return;
     const uint64_t e = first + i;
+    arr[(e >> 6) * (np * 64ull) + q * 64ull + (e & 63)] = src[i];
+}
+__global__ __launch_bounds__(YH_BLOCK) void k_gather_plane(const float* __restrict__ arr, float* __restrict__ dst,
+                                                           uint32_t np, uint32_t q, uint64_t first, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t e = first + i;
+    dst[i] = arr[(e >> 6) * (np * 64ull) + q * 64ull + (e & 63)];
+}
+
+// Stage 1 alone: batched Mat4.compose (math3d.zig:816-822) into 16 plain planes of `out_stride` floats.
+__global__ __launch_bounds__(YH_BLOCK) void k_compose(const float* __restrict__ trs, float* __restrict__ out,
+                                                      uint64_t out_stride, uint64_t first, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;
+    if (i >= count) return;
     float t[10];
-#pragma unroll
-    for (int q = 0; q < 10; ++q) t[q] = trs[(uint64_t)q * S + e];
+    load_row<10>(trs, (uint32_t)(first + i), t);
     const M4 l = m4_compose(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
 #pragma unroll
     for (int q = 0; q < 16; ++q) out[(uint64_t)q * out_stride + i] = l.v[q];
 }
 
 // ---------------------------------------------------------------------------------------------------
-// flecs column import/export: 68-byte rows {f32 m[16]; u8 dirty; u8 pad[3]} (transform.zig:8-12) <-> SoA.
-// A workgroup moves 256 rows = 4352 dwords with coalesced dword accesses on the AoS side and transposes
-// through LDS; the row stride of 17 dwords is odd, so both LDS phases are bank-conflict free.
+// flecs column import/export: 68-byte rows {f32 m[16]; u8 dirty; u8 pad[3]} (transform.zig:8-12) <-> chunked
+// planes.  A workgroup moves 256 rows = 4352 dwords with coalesced dword accesses on the AoS side and
+// transposes through LDS; the row stride of 17 dwords is odd, so both LDS phases are bank-conflict free.
 __global__ __launch_bounds__(YH_BLOCK) void k_aos68_to_soa(const uint32_t* __restrict__ rows, uint64_t count,
-                                                           float* __restrict__ planes, uint8_t* __restrict__ dirty,
-                                                           uint64_t S, uint64_t first) {
+                                                           float* __restrict__ arr, uint8_t* __restrict__ dirty,
+                                                           uint64_t first) {
     __shared__ uint32_t tile[YH_BLOCK * 17];
     const uint64_t r0 = (uint64_t)blockIdx.x * YH_BLOCK;
     const uint64_t nrows = (count - r0 < YH_BLOCK) ? (count - r0) : YH_BLOCK;
@@ -289,23 +452,25 @@ __global__ __launch_bounds__(YH_BLOCK) void k_aos68_to_soa(const uint32_t* __res
     for (uint32_t i = threadIdx.x; i < ndw; i += YH_BLOCK) tile[i] = rows[r0 * 17 + i];
     __syncthreads();
     if (threadIdx.x < nrows) {
-        const uint64_t e = first + r0 + threadIdx.x;
+        const uint32_t e = (uint32_t)(first + r0 + threadIdx.x);
+        const uint64_t off = eoff<16>(e);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) planes[(uint64_t)q * S + e] = __uint_as_float(tile[threadIdx.x * 17 + q]);
+        for (int q = 0; q < 16; ++q) ste(arr, off, q, __uint_as_float(tile[threadIdx.x * 17 + q]));
         dirty[e] = (uint8_t)((tile[threadIdx.x * 17 + 16] & 0xFFu) != 0);
     }
 }
 
-__global__ __launch_bounds__(YH_BLOCK) void k_soa_to_aos68(const float* __restrict__ planes,
-                                                           const uint8_t* __restrict__ dirty, uint64_t S, uint64_t first,
+__global__ __launch_bounds__(YH_BLOCK) void k_soa_to_aos68(const float* __restrict__ arr,
+                                                           const uint8_t* __restrict__ dirty, uint64_t first,
                                                            uint64_t count, uint32_t* __restrict__ rows) {
     __shared__ uint32_t tile[YH_BLOCK * 17];
     const uint64_t r0 = (uint64_t)blockIdx.x * YH_BLOCK;
     const uint64_t nrows = (count - r0 < YH_BLOCK) ? (count - r0) : YH_BLOCK;
     if (threadIdx.x < nrows) {
-        const uint64_t e = first + r0 + threadIdx.x;
+        const uint32_t e = (uint32_t)(first + r0 + threadIdx.x);
+        const uint64_t off = eoff<16>(e);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) tile[threadIdx.x * 17 + q] = __float_as_uint(planes[(uint64_t)q * S + e]);
+        for (int q = 0; q < 16; ++q) tile[threadIdx.x * 17 + q] = __float_as_uint(lde(arr, off, q));
         tile[threadIdx.x * 17 + 16] = dirty ? (uint32_t)(dirty[e] != 0) : 0u;  // bool + 3 zero pad bytes
     }
     __syncthreads();
@@ -317,15 +482,16 @@ __global__ __launch_bounds__(YH_BLOCK) void k_soa_to_aos68(const float* __restri
 // Synthetic scene generator: TRS + bounds from the counter-based hash, bit-identical to
 // the oracle's host generator.  Level 0 (local index < n_level0) draws from the wide ranges.
 __global__ __launch_bounds__(YH_BLOCK) void k_synth(float* __restrict__ trs, float* __restrict__ bounds,
-                                                    uint32_t* __restrict__ mesh_id, uint32_t n_meshes, uint64_t S,
-                                                    uint64_t n, uint64_t n_level0, uint64_t seed, uint64_t index_base) {
+                                                    uint32_t* __restrict__ mesh_id, uint32_t n_meshes, uint64_t n,
+                                                    uint64_t n_level0, uint64_t seed, uint64_t index_base) {
     const uint64_t e = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;
     if (e >= n) return;
     const uint64_t g = index_base + e;
     const bool top = e < n_level0;
     const float tr = top ? 100.0f : 5.0f;
+    float t[10];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) trs[(uint64_t)c * S + e] = yh_synth_uniform(seed, (uint32_t)c, g, -tr, tr);
+    for (int c = 0; c < 3; ++c) t[c] = yh_synth_uniform(seed, (uint32_t)c, g, -tr, tr);
     float q[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) q[c] = yh_synth_uniform(seed, 3u + (uint32_t)c, g, -1.0f, 1.0f);
@@ -338,17 +504,20 @@ __global__ __launch_bounds__(YH_BLOCK) void k_synth(float* __restrict__ trs, flo
         q[3] = 1.0f;
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) trs[(uint64_t)(3 + c) * S + e] = q[c];
+    for (int c = 0; c < 4; ++c) t[3 + c] = q[c];
     const float slo = top ? 0.5f : 0.8f, shi = top ? 2.0f : 1.25f;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) trs[(uint64_t)(7 + c) * S + e] = yh_synth_uniform(seed, 7u + (uint32_t)c, g, slo, shi);
+    for (int c = 0; c < 3; ++c) t[7 + c] = yh_synth_uniform(seed, 7u + (uint32_t)c, g, slo, shi);
+    store_row<10>(trs, (uint32_t)e, t);
     if (bounds) {
+        float b[6];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float h = yh_synth_uniform(seed, 10u + (uint32_t)c, g, 0.25f, 2.0f);
-            bounds[(uint64_t)c * S + e] = -h;
-            bounds[(uint64_t)(3 + c) * S + e] = h;
+            b[c] = -h;
+            b[3 + c] = h;
         }
+        store_row<6>(bounds, (uint32_t)e, b);
     }
     if (mesh_id) mesh_id[e] = (uint32_t)(yh_synth_raw(seed, 13, g) >> 32) % n_meshes;
 }

@@ -53,8 +53,14 @@ struct yh_scene {
     uint8_t* ldirty = nullptr;
     uint8_t* wdirty = nullptr;
     uint32_t* draw[YH_MAX_FRUSTA] = {};
-    uint32_t* counts = nullptr;       // device: 8 visible + 8 boundary
-    uint32_t* h_counts = nullptr;     // pinned mirror
+    uint32_t* counts = nullptr;       // device: 8 visible + 8 boundary totals, then tile counts, then visibility words
+    uint32_t* tilecnt = nullptr;      // inside the counts allocation: [n_frusta][n_tiles]
+    uint64_t* vismask = nullptr;      // inside the counts allocation: [n_frusta][n_chunks]
+    uint64_t vis_bytes = 0;           // bytes of the counts allocation (zeroed at the start of every frame)
+    uint32_t n_chunks = 0, n_tiles = 0;
+    uint32_t* h_counts = nullptr;     // host-mapped: written by k_expand ([f] totals, [8+f] boundary counts)
+    uint32_t* h_counts_dev = nullptr; // device address of h_counts
+    uint32_t bparity = 0;             // which of the two boundary-counter sets this frame uses
     void* staging = nullptr;          // device staging for AoS68 import/export
     uint64_t staging_bytes = 0;
     std::vector<uint32_t> level_offsets;
@@ -205,7 +211,7 @@ extern "C" void yh_scene_destroy(yh_scene* s) { scene_free(s); }
 extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** out) {
     if (!ctx || !d || !out) return fail(ctx, YH_ERR_BAD_ARG, "yh_scene_create: NULL argument");
     *out = nullptr;
-    ARG_TRY(ctx, d->n_entities >= 1 && d->n_entities <= 0xFFFFFFFEull, "yh_scene_create: n_entities must be in [1, 2^32-2]");
+    ARG_TRY(ctx, d->n_entities >= 1 && d->n_entities <= (1ull << 30), "yh_scene_create: n_entities must be in [1, 2^30]");
     ARG_TRY(ctx, d->n_levels >= 1 && d->n_levels <= YH_MAX_LEVELS, "yh_scene_create: n_levels must be in [1, 64]");
     ARG_TRY(ctx, d->n_frusta <= YH_MAX_FRUSTA, "yh_scene_create: n_frusta exceeds YH_MAX_FRUSTA");
     ARG_TRY(ctx, d->local_kind <= YH_LOCAL_MAT4, "yh_scene_create: bad local_kind");
@@ -240,22 +246,38 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
         alloc((void**)&s->mesh_id, S * 4);
     }
     for (uint32_t f = 0; f < d->n_frusta; ++f) alloc((void**)&s->draw[f], s->draw_cap * 4);
-    alloc((void**)&s->counts, 2 * YH_MAX_FRUSTA * 4);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counts, 2 * YH_MAX_FRUSTA * 4, hipHostMallocDefault);
+    // stage-3 buffers: one allocation = 16 total words | tile counts | visibility words (8-byte aligned);
+    // only the totals and the words need zeroing each frame (tile counts are fully rewritten by k_count)
+    s->n_chunks = (uint32_t)(S / YH_CHUNK);
+    s->n_tiles = (s->n_chunks + YH_EXPAND_WORDS - 1) / YH_EXPAND_WORDS;
+    const uint64_t F_alloc = d->n_frusta ? d->n_frusta : 1;
+    const uint64_t tile_words = (F_alloc * s->n_tiles + 1) & ~1ull;
+    s->vis_bytes = (4 * YH_MAX_FRUSTA + tile_words) * 4 + F_alloc * s->n_chunks * 8;
+    alloc((void**)&s->counts, s->vis_bytes);
+    if (e == hipSuccess) {
+        s->tilecnt = s->counts + 4 * YH_MAX_FRUSTA;  // [0,8) totals, [8,16) and [16,24) boundary counters (two parities)
+        s->vismask = (uint64_t*)(s->tilecnt + tile_words);
+    }
+    if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counts, 2 * YH_MAX_FRUSTA * 4, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&s->h_counts_dev, s->h_counts, 0);
     if (e == hipSuccess) e = hipEventCreate(&s->ev0);
     if (e == hipSuccess) e = hipEventCreate(&s->ev1);
     // world = IDENTITY, dirty: LocalTransform.onAdd (transform.zig:38-44)
     if (e == hipSuccess) e = hipMemsetAsync(s->world, 0, 16 * S * 4, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->ldirty, 1, S, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->wdirty, 1, S, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(s->counts, 0, 2 * YH_MAX_FRUSTA * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->counts, 0, s->vis_bytes, ctx->stream);
     if (e == hipSuccess) {
         memset(s->h_counts, 0, 2 * YH_MAX_FRUSTA * 4);
         const float one = 1.0f;
         uint32_t bits;
         memcpy(&bits, &one, 4);
-        for (int p : {0, 5, 10, 15})
-            if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(s->world + (uint64_t)p * S), (int)bits, S, ctx->stream);
+        (void)bits;
+        for (int p : {0, 5, 10, 15}) {
+            hipLaunchKernelGGL(k_fill_plane, dim3(cdiv(s->n, YH_BLOCK)), dim3(YH_BLOCK), 0, ctx->stream, s->world, 16u,
+                               (uint32_t)p, one, s->n);
+            if (e == hipSuccess) e = hipGetLastError();
+        }
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -344,21 +366,51 @@ extern "C" int yh_set_root(yh_scene* s, const float root_world[16]) {
     return YH_OK;
 }
 
-static int copy_planes_h2d(yh_scene* s, float* dev, const float* const* planes, int np, uint64_t first, uint64_t count) {
+static int ensure_staging(yh_scene* s, uint64_t bytes);
+
+// elements per staging pass of plane uploads / downloads
+#define YH_PLANE_CHUNK (16ull << 20)
+
+// Host planes -> chunked device array `dev` (np_total planes per chunk), planes [q0, q0+np).
+static int copy_planes_h2d(yh_scene* s, float* dev, uint32_t np_total, uint32_t q0, const float* const* planes, int np,
+                           uint64_t first, uint64_t count) {
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    if (count == 0) return YH_OK;
+    const uint64_t chunk = std::min<uint64_t>(count, YH_PLANE_CHUNK);
+    if (int rc = ensure_staging(s, chunk * 4)) return rc;
+    hipStream_t st = s->ctx->stream;
     for (int p = 0; p < np; ++p) {
         ARG_TRY(s->ctx, planes[p], "plane pointer is NULL");
-        HIP_TRY(s->ctx, hipMemcpy(dev + (uint64_t)p * s->stride + first, planes[p], count * 4, hipMemcpyHostToDevice));
+        for (uint64_t done = 0; done < count; done += chunk) {
+            const uint64_t c = std::min<uint64_t>(chunk, count - done);
+            HIP_TRY(s->ctx, hipMemcpyAsync(s->staging, planes[p] + done, c * 4, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_scatter_plane, dim3(cdiv(c, YH_BLOCK)), dim3(YH_BLOCK), 0, st, (const float*)s->staging, dev,
+                               np_total, q0 + (uint32_t)p, first + done, c);
+            HIP_TRY(s->ctx, hipGetLastError());
+            HIP_TRY(s->ctx, hipStreamSynchronize(st));
+        }
     }
     return YH_OK;
 }
 
-static int copy_planes_d2h(yh_scene* s, const float* dev, float* const* planes, int np, uint64_t first, uint64_t count) {
+static int copy_planes_d2h(yh_scene* s, const float* dev, uint32_t np_total, uint32_t q0, float* const* planes, int np,
+                           uint64_t first, uint64_t count) {
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     if (int rc = sync_scene(s)) return rc;
+    if (count == 0) return YH_OK;
+    const uint64_t chunk = std::min<uint64_t>(count, YH_PLANE_CHUNK);
+    if (int rc = ensure_staging(s, chunk * 4)) return rc;
+    hipStream_t st = s->ctx->stream;
     for (int p = 0; p < np; ++p) {
         ARG_TRY(s->ctx, planes[p], "plane pointer is NULL");
-        HIP_TRY(s->ctx, hipMemcpy(planes[p], dev + (uint64_t)p * s->stride + first, count * 4, hipMemcpyDeviceToHost));
+        for (uint64_t done = 0; done < count; done += chunk) {
+            const uint64_t c = std::min<uint64_t>(chunk, count - done);
+            hipLaunchKernelGGL(k_gather_plane, dim3(cdiv(c, YH_BLOCK)), dim3(YH_BLOCK), 0, st, dev, (float*)s->staging,
+                               np_total, q0 + (uint32_t)p, first + done, c);
+            HIP_TRY(s->ctx, hipGetLastError());
+            HIP_TRY(s->ctx, hipMemcpyAsync(planes[p] + done, s->staging, c * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(s->ctx, hipStreamSynchronize(st));
+        }
     }
     return YH_OK;
 }
@@ -367,14 +419,14 @@ extern "C" int yh_upload_trs(yh_scene* s, const float* const planes[10], uint64_
     if (int rc = check_range(s, "yh_upload_trs", first, count)) return rc;
     ARG_TRY(s->ctx, planes, "yh_upload_trs: planes is NULL");
     if (s->desc.local_kind != YH_LOCAL_TRS) return fail(s->ctx, YH_ERR_STATE, "yh_upload_trs: scene holds Mat4 locals");
-    return copy_planes_h2d(s, s->trs, planes, 10, first, count);
+    return copy_planes_h2d(s, s->trs, 10, 0, planes, 10, first, count);
 }
 
 extern "C" int yh_download_trs(yh_scene* s, float* const planes[10], uint64_t first, uint64_t count) {
     if (int rc = check_range(s, "yh_download_trs", first, count)) return rc;
     ARG_TRY(s->ctx, planes, "yh_download_trs: planes is NULL");
     if (s->desc.local_kind != YH_LOCAL_TRS) return fail(s->ctx, YH_ERR_STATE, "yh_download_trs: scene holds Mat4 locals");
-    return copy_planes_d2h(s, s->trs, planes, 10, first, count);
+    return copy_planes_d2h(s, s->trs, 10, 0, planes, 10, first, count);
 }
 
 extern "C" int yh_upload_aabb(yh_scene* s, const float* const min_planes[3], const float* const max_planes[3],
@@ -382,8 +434,8 @@ extern "C" int yh_upload_aabb(yh_scene* s, const float* const min_planes[3], con
     if (int rc = check_range(s, "yh_upload_aabb", first, count)) return rc;
     ARG_TRY(s->ctx, min_planes && max_planes, "yh_upload_aabb: NULL argument");
     if (s->desc.bounds_kind != YH_BOUNDS_PER_ENTITY) return fail(s->ctx, YH_ERR_STATE, "yh_upload_aabb: scene has no per-entity bounds");
-    if (int rc = copy_planes_h2d(s, s->bounds, min_planes, 3, first, count)) return rc;
-    return copy_planes_h2d(s, s->bounds + 3 * s->stride, max_planes, 3, first, count);
+    if (int rc = copy_planes_h2d(s, s->bounds, 6, 0, min_planes, 3, first, count)) return rc;
+    return copy_planes_h2d(s, s->bounds, 6, 3, max_planes, 3, first, count);
 }
 
 extern "C" int yh_download_aabb(yh_scene* s, float* const min_planes[3], float* const max_planes[3], uint64_t first,
@@ -391,8 +443,8 @@ extern "C" int yh_download_aabb(yh_scene* s, float* const min_planes[3], float* 
     if (int rc = check_range(s, "yh_download_aabb", first, count)) return rc;
     ARG_TRY(s->ctx, min_planes && max_planes, "yh_download_aabb: NULL argument");
     if (s->desc.bounds_kind != YH_BOUNDS_PER_ENTITY) return fail(s->ctx, YH_ERR_STATE, "yh_download_aabb: scene has no per-entity bounds");
-    if (int rc = copy_planes_d2h(s, s->bounds, min_planes, 3, first, count)) return rc;
-    return copy_planes_d2h(s, s->bounds + 3 * s->stride, max_planes, 3, first, count);
+    if (int rc = copy_planes_d2h(s, s->bounds, 6, 0, min_planes, 3, first, count)) return rc;
+    return copy_planes_d2h(s, s->bounds, 6, 3, max_planes, 3, first, count);
 }
 
 extern "C" int yh_upload_mesh_aabbs(yh_scene* s, const float* table, uint32_t n_meshes) {
@@ -441,7 +493,7 @@ static int upload_aos68(yh_scene* s, const void* column, uint64_t first, uint64_
         const uint64_t c = std::min<uint64_t>(YH_AOS_CHUNK, count - done);
         HIP_TRY(s->ctx, hipMemcpyAsync(s->staging, src + done * 68, c * 68, hipMemcpyHostToDevice, s->ctx->stream));
         hipLaunchKernelGGL(k_aos68_to_soa, dim3(cdiv(c, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream,
-                           (const uint32_t*)s->staging, c, planes, dirty, s->stride, first + done);
+                           (const uint32_t*)s->staging, c, planes, dirty, first + done);
         HIP_TRY(s->ctx, hipGetLastError());
         HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
     }
@@ -456,7 +508,7 @@ static int download_aos68(yh_scene* s, void* column, uint64_t first, uint64_t co
     for (uint64_t done = 0; done < count; done += YH_AOS_CHUNK) {
         const uint64_t c = std::min<uint64_t>(YH_AOS_CHUNK, count - done);
         hipLaunchKernelGGL(k_soa_to_aos68, dim3(cdiv(c, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream, planes, dirty,
-                           s->stride, first + done, c, (uint32_t*)s->staging);
+                           first + done, c, (uint32_t*)s->staging);
         HIP_TRY(s->ctx, hipGetLastError());
         HIP_TRY(s->ctx, hipMemcpyAsync(dst + done * 68, s->staging, c * 68, hipMemcpyDeviceToHost, s->ctx->stream));
         HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
@@ -493,7 +545,7 @@ extern "C" int yh_download_local_aos68(yh_scene* s, void* column, uint64_t first
 extern "C" int yh_download_world_soa(yh_scene* s, float* const planes[16], uint64_t first, uint64_t count) {
     if (int rc = check_range(s, "yh_download_world_soa", first, count)) return rc;
     ARG_TRY(s->ctx, planes, "yh_download_world_soa: planes is NULL");
-    return copy_planes_d2h(s, s->world, planes, 16, first, count);
+    return copy_planes_d2h(s, s->world, 16, 0, planes, 16, first, count);
 }
 
 extern "C" int yh_mark_dirty(yh_scene* s, int local, int world, uint64_t first, uint64_t count) {
@@ -518,7 +570,7 @@ extern "C" int yh_compose(yh_scene* s, float* const planes[16], uint64_t first, 
     for (uint64_t done = 0; done < count; done += chunk) {
         const uint64_t c = std::min<uint64_t>(chunk, count - done);
         hipLaunchKernelGGL(k_compose, dim3(cdiv(c, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream, s->trs, (float*)s->staging,
-                           s->stride, chunk, first + done, c);
+                           chunk, first + done, c);
         HIP_TRY(s->ctx, hipGetLastError());
         HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
         for (int p = 0; p < 16; ++p) {
@@ -536,29 +588,48 @@ static void allow_big_lds(K kernel) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 }
 
-template <int G, int BOUNDS>
+template <int G, int BOUNDS, bool HAS_BASE, bool PREFETCH>
 static void launch_trs_g(dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a) {
-    static bool once = (allow_big_lds(k_frame_trs<G, BOUNDS>), true);
+    static bool once = (allow_big_lds(k_frame_trs<G, BOUNDS, HAS_BASE, PREFETCH>), true);
     (void)once;
-    hipLaunchKernelGGL((k_frame_trs<G, BOUNDS>), grid, dim3(YH_BLOCK), lds, st, a);
+    hipLaunchKernelGGL((k_frame_trs<G, BOUNDS, HAS_BASE, PREFETCH>), grid, dim3(YH_BLOCK), lds, st, a);
 }
 
-template <int BOUNDS>
-static void launch_trs(int G, dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a) {
+template <int BOUNDS, bool HAS_BASE, bool PREFETCH>
+static void launch_trs_b(int G, dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a) {
     switch (G) {
-        case 1: launch_trs_g<1, BOUNDS>(grid, lds, st, a); break;
-        case 2: launch_trs_g<2, BOUNDS>(grid, lds, st, a); break;
+        case 1: launch_trs_g<1, BOUNDS, HAS_BASE, PREFETCH>(grid, lds, st, a); break;
+        case 2: launch_trs_g<2, BOUNDS, HAS_BASE, PREFETCH>(grid, lds, st, a); break;
         case 3:
-        case 4: launch_trs_g<4, BOUNDS>(grid, lds, st, a); break;
-        default: launch_trs_g<8, BOUNDS>(grid, lds, st, a); break;
+        case 4: launch_trs_g<4, BOUNDS, HAS_BASE, PREFETCH>(grid, lds, st, a); break;
+        default: launch_trs_g<8, BOUNDS, HAS_BASE, PREFETCH>(grid, lds, st, a); break;
     }
 }
 
 template <int BOUNDS>
-static void launch_mat4(dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
-    static bool once = (allow_big_lds(k_level_mat4<BOUNDS>), true);
-    (void)once;
-    hipLaunchKernelGGL((k_level_mat4<BOUNDS>), grid, dim3(YH_BLOCK), lds, st, a, root_dirty);
+static void launch_trs(int G, bool has_base, dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a) {
+    static const char* pf_env = getenv("YH_TUNE_PREFETCH");  // tuning knob: 0 / 1, default: on when iters > 1
+    const bool prefetch = pf_env ? (atoi(pf_env) != 0) : false;  // measured: occupancy beats the register double buffer
+    if (has_base) {
+        if (prefetch) launch_trs_b<BOUNDS, true, true>(G, grid, lds, st, a);
+        else launch_trs_b<BOUNDS, true, false>(G, grid, lds, st, a);
+    } else {
+        if (prefetch) launch_trs_b<BOUNDS, false, true>(G, grid, lds, st, a);
+        else launch_trs_b<BOUNDS, false, false>(G, grid, lds, st, a);
+    }
+}
+
+template <int BOUNDS>
+static void launch_mat4(bool has_base, dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
+    if (has_base) {
+        static bool once = (allow_big_lds(k_level_mat4<BOUNDS, true>), true);
+        (void)once;
+        hipLaunchKernelGGL((k_level_mat4<BOUNDS, true>), grid, dim3(YH_BLOCK), lds, st, a, root_dirty);
+    } else {
+        static bool once = (allow_big_lds(k_level_mat4<BOUNDS, false>), true);
+        (void)once;
+        hipLaunchKernelGGL((k_level_mat4<BOUNDS, false>), grid, dim3(YH_BLOCK), lds, st, a, root_dirty);
+    }
 }
 
 static int ensure_kev(yh_scene* s) {
@@ -596,20 +667,28 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     a.world = s->world;
     a.ldirty = s->ldirty;
     a.wdirty = s->wdirty;
-    a.counts = s->counts;
-    for (uint32_t f = 0; f < YH_MAX_FRUSTA; ++f) a.draw[f] = s->draw[f];
-    a.stride = s->stride;
-    a.draw_cap = s->draw_cap;
+    a.bcount = s->counts + YH_MAX_FRUSTA * (1 + s->bparity);
+    a.vismask = s->vismask;
+    a.n_chunks = s->n_chunks;
     a.n_frusta = cull ? n_frusta : 0;
     a.id_base = s->desc.id_base;
     a.n_meshes = s->n_meshes;
     memcpy(a.root, s->root, sizeof a.root);
     if (cull) memcpy(a.planes, planes, (size_t)n_frusta * 24 * sizeof(float));
     const int bounds = cull ? (int)s->desc.bounds_kind : 0;
-    const size_t lds = (32 + (size_t)a.n_frusta * YH_TILE) * sizeof(uint32_t);
+    // slices per workgroup: with more than one slice the next slice's inputs are prefetched while the current one
+    // is computed; small launches keep one slice per workgroup so that the grid fills the chip
+    auto pick_iters = [](uint64_t n_launch) -> uint32_t {
+        static const char* it_env = getenv("YH_TUNE_ITERS");  // tuning knob
+        if (it_env) return (uint32_t)std::min<int>(std::max<int>(atoi(it_env), 1), YH_MAX_ITERS);
+        return n_launch >= 256 * 1024 ? 2u : 1u;  // measured: 2 slices per workgroup once the grid fills the chip
+    };
+    auto lds_bytes = [&](uint32_t) -> size_t { return 0; };
+    auto grid_for = [&](const FrameArgs& fa) -> dim3 {
+        return dim3(cdiv((uint64_t)fa.end - (fa.begin & ~63u), (uint64_t)fa.iters * YH_BLOCK));
+    };
 
     if (s->kernel_timing) HIP_TRY(ctx, hipEventRecord(s->ev0, st));
-    HIP_TRY(ctx, hipMemsetAsync(s->counts, 0, 2 * YH_MAX_FRUSTA * 4, st));
     uint32_t launches = 0;
     if (s->kernel_timing)
         if (int rc = ensure_kev(s)) return rc;
@@ -635,15 +714,17 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
             a.begin = s->level_offsets[g.lo];
             a.end = s->level_offsets[g.hi + 1];
             if (a.end == a.begin) continue;
-            a.has_base = g.lo > 0;
+            const bool has_base = g.lo > 0;
             for (uint32_t j = 0; j < YH_MAX_GROUP; ++j)
                 a.lvl_begin[j] = (g.lo + 1 + j <= g.hi) ? s->level_offsets[g.lo + 1 + j] : 0xFFFFFFFFu;
-            const dim3 grid(cdiv((uint64_t)a.end - a.begin, YH_TILE));
+            a.iters = pick_iters((uint64_t)a.end - a.begin);
+            const size_t lds = lds_bytes(a.iters);
+            const dim3 grid = grid_for(a);
             const int G = (int)(g.hi - g.lo + 1);
             if (int rc = time_begin(gi)) return rc;
-            if (bounds == 0) launch_trs<0>(G, grid, lds, st, a);
-            else if (bounds == 1) launch_trs<1>(G, grid, lds, st, a);
-            else launch_trs<2>(G, grid, lds, st, a);
+            if (bounds == 0) launch_trs<0>(G, has_base, grid, lds, st, a);
+            else if (bounds == 1) launch_trs<1>(G, has_base, grid, lds, st, a);
+            else launch_trs<2>(G, has_base, grid, lds, st, a);
             HIP_TRY(ctx, hipGetLastError());
             if (int rc = time_end()) return rc;
             ++launches;
@@ -654,12 +735,14 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
             a.begin = s->level_offsets[k];
             a.end = s->level_offsets[k + 1];
             if (a.end == a.begin) continue;
-            a.has_base = k > 0;
-            const dim3 grid(cdiv((uint64_t)a.end - a.begin, YH_TILE));
+            const bool has_base = k > 0;
+            a.iters = pick_iters((uint64_t)a.end - a.begin);
+            const size_t lds = lds_bytes(a.iters);
+            const dim3 grid = grid_for(a);
             if (int rc = time_begin(k)) return rc;
-            if (bounds == 0) launch_mat4<0>(grid, lds, st, a, s->root_dirty);
-            else if (bounds == 1) launch_mat4<1>(grid, lds, st, a, s->root_dirty);
-            else launch_mat4<2>(grid, lds, st, a, s->root_dirty);
+            if (bounds == 0) launch_mat4<0>(has_base, grid, lds, st, a, s->root_dirty);
+            else if (bounds == 1) launch_mat4<1>(has_base, grid, lds, st, a, s->root_dirty);
+            else launch_mat4<2>(has_base, grid, lds, st, a, s->root_dirty);
             HIP_TRY(ctx, hipGetLastError());
             if (int rc = time_end()) return rc;
             ++launches;
@@ -671,7 +754,35 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         ++launches;
     }
     s->root_dirty = 0;  // the world sweep clears the root's flag too
-    HIP_TRY(ctx, hipMemcpyAsync(s->h_counts, s->counts, 2 * YH_MAX_FRUSTA * 4, hipMemcpyDeviceToHost, st));
+    if (cull) {
+        // stage 3, part 2: tile prefix sums + expansion of the visibility words into ordered draw lists
+        ExpandArgs x;
+        memset(&x, 0, sizeof x);
+        x.vismask = s->vismask;
+        x.tilecnt = s->tilecnt;
+        x.counts = s->counts;
+        x.bcount_cur = s->counts + YH_MAX_FRUSTA * (1 + s->bparity);
+        x.bcount_next = s->counts + YH_MAX_FRUSTA * (2 - s->bparity);
+        x.host_counts = s->h_counts_dev;
+        s->bparity ^= 1u;
+        for (uint32_t f = 0; f < YH_MAX_FRUSTA; ++f) x.draw[f] = s->draw[f];
+        x.draw_cap = s->draw_cap;
+        x.n_chunks = s->n_chunks;
+        x.n_tiles = s->n_tiles;
+        x.id_base = s->desc.id_base;
+        static const char* sc_env = getenv("YH_TUNE_SELFCOUNT");  // tuning knob
+        x.self_count = s->n_tiles <= (sc_env ? (uint32_t)atoi(sc_env) : (uint32_t)YH_SELF_COUNT_TILES);
+        if (int rc = time_begin(YH_MAX_LEVELS - 1)) return rc;
+        if (!x.self_count) {
+            hipLaunchKernelGGL(k_count, dim3(s->n_tiles, n_frusta), dim3(YH_BLOCK), 0, st, x);
+            HIP_TRY(ctx, hipGetLastError());
+            ++launches;
+        }
+        hipLaunchKernelGGL(k_expand, dim3(s->n_tiles, n_frusta), dim3(YH_BLOCK), 0, st, x);
+        HIP_TRY(ctx, hipGetLastError());
+        if (int rc = time_end()) return rc;
+        ++launches;
+    }
     if (s->kernel_timing) HIP_TRY(ctx, hipEventRecord(s->ev1, st));
     s->frame_timed = s->kernel_timing;
     s->frame_pending = true;
@@ -896,7 +1007,7 @@ extern "C" int yh_scene_fill_synthetic(yh_scene* s, const yh_synth_desc* d) {
     }
     hipLaunchKernelGGL(k_synth, dim3(cdiv(s->n, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream, s->trs,
                        s->desc.bounds_kind == YH_BOUNDS_PER_ENTITY ? s->bounds : (float*)nullptr,
-                       table ? s->mesh_id : (uint32_t*)nullptr, table ? s->n_meshes : 1u, s->stride, s->n,
+                       table ? s->mesh_id : (uint32_t*)nullptr, table ? s->n_meshes : 1u, s->n,
                        (uint64_t)s->level_offsets[1], d->seed, d->index_base);
     HIP_TRY(s->ctx, hipGetLastError());
     return sync_scene(s);
