@@ -163,7 +163,8 @@ int yh_timings(yh_scene* s, yh_timing* out);
 /* Measurement harness (no reference counterpart): HIP events around every launch of yh_frame, on the
  * context's stream.  yh_scene_get_groups writes up to cap (first_level, last_level, first_entity,
  * end_entity) quadruples, one per launch; yh_scene_get_group_timings the mean device time per launch
- * since the previous call (at most 2048 launches are recorded between calls).                           */
+ * since the previous call (at most 2048 launches are recorded between calls).  enable: 0 = off, 1 = every
+ * launch plus the frame, 2 + i = only launch i of the frame (two event records per frame).               */
 int yh_scene_set_kernel_timing(yh_scene* s, int enable);
 int yh_scene_get_groups(yh_scene* s, uint32_t* quads, uint32_t cap, uint32_t* n_groups);
 int yh_scene_get_group_timings(yh_scene* s, float* mean_ms, uint32_t* samples, uint32_t cap);

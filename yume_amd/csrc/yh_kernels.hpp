@@ -292,14 +292,15 @@ __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, cons
 }
 
 // ---- stage 3 back end, part 2: prefix sums + expansion into ordered draw lists -----------------------------
-// An expand tile is 256 visibility words (16384 entities).  k_count reduces every tile to its visible count;
-// k_expand gives one workgroup to each (tile, frustum): its base is the sum of the tile counts before it (read
-// redundantly: <= a few thousand L2-resident words, cheaper than a dependent scan launch), the 256 words are
-// prefix-summed through LDS and the 4 waves expand them round-robin, one word per step: lane l emits entity
-// chunk*64+l at rank mbcnt(word).  Ascending entity order, coalesced stores, no atomics.  Scenes of at most
-// YH_SELF_COUNT_TILES tiles skip k_count: every workgroup popcounts the words before its tile itself.
-#define YH_EXPAND_WORDS 256
-#define YH_SELF_COUNT_TILES 64
+// An expand tile is `words` visibility words (64 = 4096 entities, or 256 for scenes beyond 16M entities).
+// k_count reduces every tile to its visible count; k_expand gives one workgroup to each (tile, frustum): its base
+// is the sum of the tile counts before it (read redundantly: a few thousand L2-resident words, cheaper than a
+// dependent scan launch), the tile's words are prefix-summed through LDS and the 4 waves expand them
+// round-robin, one word per step: lane l emits entity chunk*64+l at rank mbcnt(word).  Ascending entity order,
+// coalesced stores, no atomics.  Scenes of at most YH_SELF_COUNT_TILES tiles skip k_count: every workgroup
+// popcounts the words before its tile itself.
+#define YH_EXPAND_WORDS_MAX 256
+#define YH_SELF_COUNT_TILES 8
 
 struct ExpandArgs {
     const uint64_t* vismask;
@@ -311,6 +312,7 @@ struct ExpandArgs {
     uint32_t* draw[YH_K_MAX_FRUSTA];
     uint64_t draw_cap;
     uint32_t n_chunks, n_tiles, id_base, self_count;
+    uint32_t words;  // visibility words per tile: 64 or 256
 };
 
 __device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* s_red) {
@@ -326,8 +328,8 @@ __device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* s_red) {
 __global__ __launch_bounds__(YH_BLOCK) void k_count(const ExpandArgs x) {
     __shared__ uint32_t s_red[4];
     const uint32_t t = blockIdx.x, f = blockIdx.y;
-    const uint32_t c = t * YH_EXPAND_WORDS + threadIdx.x;
-    const uint64_t m = c < x.n_chunks ? x.vismask[(uint64_t)f * x.n_chunks + c] : 0ull;
+    const uint32_t c = t * x.words + threadIdx.x;
+    const uint64_t m = (threadIdx.x < x.words && c < x.n_chunks) ? x.vismask[(uint64_t)f * x.n_chunks + c] : 0ull;
     const uint32_t total = block_sum_256((uint32_t)__popcll(m), s_red);
     if (threadIdx.x == 0) x.tilecnt[f * x.n_tiles + t] = total;
 }
@@ -339,9 +341,9 @@ __global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t t = blockIdx.x, f = blockIdx.y;
     const uint64_t* __restrict__ masks = x.vismask + (uint64_t)f * x.n_chunks;
-    const uint32_t c0 = t * YH_EXPAND_WORDS;
+    const uint32_t c0 = t * x.words;
     const uint32_t c = c0 + tid;
-    const uint64_t m = c < x.n_chunks ? masks[c] : 0ull;
+    const uint64_t m = (tid < x.words && c < x.n_chunks) ? masks[c] : 0ull;
     const uint32_t pc = (uint32_t)__popcll(m);
     // base = visible entities in the tiles before this one
     uint32_t part = 0;
@@ -377,8 +379,8 @@ __global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) {
     }
     if (own == 0) return;
     uint32_t* __restrict__ out = x.draw[f];
-    const uint32_t n_words = min((uint32_t)YH_EXPAND_WORDS, x.n_chunks - c0);
-#pragma unroll 4
+    const uint32_t n_words = min(x.words, x.n_chunks - c0);
+#pragma unroll 8
     for (uint32_t k = wv; k < n_words; k += 4) {
         const uint64_t mk = s_mask[k];  // wave-uniform
         if (mk) {

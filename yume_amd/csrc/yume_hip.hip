@@ -57,7 +57,7 @@ struct yh_scene {
     uint32_t* tilecnt = nullptr;      // inside the counts allocation: [n_frusta][n_tiles]
     uint64_t* vismask = nullptr;      // inside the counts allocation: [n_frusta][n_chunks]
     uint64_t vis_bytes = 0;           // bytes of the counts allocation (zeroed at the start of every frame)
-    uint32_t n_chunks = 0, n_tiles = 0;
+    uint32_t n_chunks = 0, n_tiles = 0, tile_words = 64;
     uint32_t* h_counts = nullptr;     // host-mapped: written by k_expand ([f] totals, [8+f] boundary counts)
     uint32_t* h_counts_dev = nullptr; // device address of h_counts
     uint32_t bparity = 0;             // which of the two boundary-counter sets this frame uses
@@ -77,6 +77,7 @@ struct yh_scene {
     uint64_t frames = 0;
     uint32_t last_launches = 0;
     bool kernel_timing = false;
+    int timing_only = -1;  // >= 0: only this launch index gets events (and no frame events)
     bool frame_timed = false;
     std::vector<hipEvent_t> kev;  // YH_TIMING_RING pairs, lazily created
     std::vector<uint32_t> kev_group;
@@ -249,7 +250,8 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
     // stage-3 buffers: one allocation = 16 total words | tile counts | visibility words (8-byte aligned);
     // only the totals and the words need zeroing each frame (tile counts are fully rewritten by k_count)
     s->n_chunks = (uint32_t)(S / YH_CHUNK);
-    s->n_tiles = (s->n_chunks + YH_EXPAND_WORDS - 1) / YH_EXPAND_WORDS;
+    s->tile_words = s->n_chunks <= 64u * 4096u ? 64u : (uint32_t)YH_EXPAND_WORDS_MAX;
+    s->n_tiles = (s->n_chunks + s->tile_words - 1) / s->tile_words;
     const uint64_t F_alloc = d->n_frusta ? d->n_frusta : 1;
     const uint64_t tile_words = (F_alloc * s->n_tiles + 1) & ~1ull;
     s->vis_bytes = (4 * YH_MAX_FRUSTA + tile_words) * 4 + F_alloc * s->n_chunks * 8;
@@ -688,20 +690,23 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         return dim3(cdiv((uint64_t)fa.end - (fa.begin & ~63u), (uint64_t)fa.iters * YH_BLOCK));
     };
 
-    if (s->kernel_timing) HIP_TRY(ctx, hipEventRecord(s->ev0, st));
+    const bool frame_events = s->kernel_timing && s->timing_only < 0;
+    if (frame_events) HIP_TRY(ctx, hipEventRecord(s->ev0, st));
     uint32_t launches = 0;
     if (s->kernel_timing)
         if (int rc = ensure_kev(s)) return rc;
 
+    bool timing_this = false;
     auto time_begin = [&](uint32_t group) -> int {
-        if (s->kernel_timing && s->kev_used < YH_TIMING_RING) {
+        timing_this = s->kernel_timing && s->kev_used < YH_TIMING_RING && (s->timing_only < 0 || (uint32_t)s->timing_only == group);
+        if (timing_this) {
             s->kev_group[s->kev_used] = group;
             HIP_TRY(ctx, hipEventRecord(s->kev[2 * s->kev_used], st));
         }
         return YH_OK;
     };
     auto time_end = [&]() -> int {
-        if (s->kernel_timing && s->kev_used < YH_TIMING_RING) {
+        if (timing_this) {
             HIP_TRY(ctx, hipEventRecord(s->kev[2 * s->kev_used + 1], st));
             ++s->kev_used;
         }
@@ -769,6 +774,7 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         x.draw_cap = s->draw_cap;
         x.n_chunks = s->n_chunks;
         x.n_tiles = s->n_tiles;
+        x.words = s->tile_words;
         x.id_base = s->desc.id_base;
         static const char* sc_env = getenv("YH_TUNE_SELFCOUNT");  // tuning knob
         x.self_count = s->n_tiles <= (sc_env ? (uint32_t)atoi(sc_env) : (uint32_t)YH_SELF_COUNT_TILES);
@@ -783,8 +789,8 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         if (int rc = time_end()) return rc;
         ++launches;
     }
-    if (s->kernel_timing) HIP_TRY(ctx, hipEventRecord(s->ev1, st));
-    s->frame_timed = s->kernel_timing;
+    if (frame_events) HIP_TRY(ctx, hipEventRecord(s->ev1, st));
+    s->frame_timed = frame_events;
     s->frame_pending = true;
     s->last_n_frusta = a.n_frusta;
     s->last_launches = launches;
@@ -855,6 +861,7 @@ extern "C" int yh_timings(yh_scene* s, yh_timing* out) {
 extern "C" int yh_scene_set_kernel_timing(yh_scene* s, int enable) {
     if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_scene_set_kernel_timing: scene is NULL");
     s->kernel_timing = enable != 0;
+    s->timing_only = enable >= 2 ? enable - 2 : -1;
     s->kev_used = 0;
     return YH_OK;
 }
