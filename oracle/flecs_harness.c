@@ -1,0 +1,194 @@
+/*
+ * flecs_harness.c — CPU ORACLE validation against the REAL flecs (test infrastructure, this container only).
+ *
+ * Links the reference's vendored flecs 4.0.4 (compiled in place from /root/reference/vendor/flecs/flecs.c by
+ * oracle/Makefile, never copied) and drives the transform path exactly the way the reference registers it:
+ *   - components LocalTransform / WorldTransform: 68 bytes, align 4, hooks onAdd / onSet
+ *     (engine/components/transform.zig:8-12, 38-51, 62-66, 92-97; registration engine/ecs.zig:110-182)
+ *   - the scene root owns a WorldTransform{IDENTITY} (engine/GameApp.zig:77,95), every entity is created
+ *     parent-first under it with a (ChildOf, parent) pair (GameApp.zig:204-215)
+ *   - TransformSyncSystem's three query terms: WorldTransform inout, LocalTransform inout, WorldTransform in
+ *     with src = Up (engine/systems/TransformSyncSystem.zig:25-37), then PostWorldTransform and
+ *     PostLocalTransform (engine/systems/PostTransformSystem.zig:12-37).
+ * The per-batch arithmetic is the oracle's restatement (yume_oracle.c) — Zig cannot be compiled here — so what
+ * this binary pins is the ECS side: which rows flecs batches together, that the `Up` field is ONE shared value
+ * per batch, parent-first table order (F5), and dirty-flag propagation across frames.
+ *
+ * usage: flecs_harness <scene.bin> <out.bin>
+ * scene.bin: "YFH1" u32 n, n_levels, n_frames | u32 level_offsets[n_levels+1] | u32 parent[n] | f32 local[n][16]
+ *            | f32 root[16] | per frame: u32 n_edits, then {u32 entity (0xFFFFFFFF = root), u32 kind (0 = local,
+ *            1 = world), f32 m[16]} applied before the frame as set + modified (editor/editors/transform.zig:76-79)
+ * out.bin:   per frame: world rows n x 68 B, local rows n x 68 B, u64 batches, u64 rows_seen, u32 up_fields_shared
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "flecs.h"
+#include "yume_oracle.h"
+
+static ecs_entity_t g_local_id, g_world_id;
+static uint64_t g_batches, g_rows;
+static uint32_t g_up_shared = 1;
+
+/* LocalTransform.onAdd (transform.zig:38-44): give the entity a WorldTransform{IDENTITY, dirty}. */
+static void local_on_add(ecs_iter_t* it) {
+    ecs_world_t* w = ecs_get_world(it->world);
+    yo_transform68 wt;
+    memset(&wt, 0, sizeof wt);
+    yo_identity(&wt.matrix);
+    wt.dirty = 1;
+    for (int i = 0; i < it->count; ++i) ecs_set_id(w, it->entities[i], g_world_id, sizeof wt, &wt);
+}
+
+/* onSet of either component (transform.zig:46-51, 92-97): dirty = true. */
+static void any_on_set(ecs_iter_t* it) {
+    yo_transform68* rows = (yo_transform68*)ecs_field_w_size(it, sizeof(yo_transform68), 0);
+    if (!rows) return;
+    for (int i = 0; i < it->count; ++i) rows[i].dirty = 1;
+}
+
+/* TransformSyncSystem.zig:41-49 -> :53-74 */
+static void transform_sync(ecs_iter_t* it) {
+    yo_transform68* wts = (yo_transform68*)ecs_field_w_size(it, sizeof(yo_transform68), 0);
+    yo_transform68* lts = (yo_transform68*)ecs_field_w_size(it, sizeof(yo_transform68), 1);
+    const yo_transform68* parent = (const yo_transform68*)ecs_field_w_size(it, sizeof(yo_transform68), 2);
+    if (ecs_field_is_self(it, 2)) g_up_shared = 0; /* the Up term must NOT be a per-row column */
+    yo_transform_sync_batch(wts, lts, parent, (size_t)it->count);
+    g_batches += 1;
+    g_rows += (uint64_t)it->count;
+}
+
+/* PostTransformSystem.zig:31-35 */
+static void post_clear(ecs_iter_t* it) {
+    yo_post_transform((yo_transform68*)ecs_field_w_size(it, sizeof(yo_transform68), 0), (size_t)it->count);
+}
+
+static ecs_entity_t make_component(ecs_world_t* w, const char* name, ecs_iter_action_t on_add) {
+    ecs_entity_desc_t ed = {0};
+    ed.use_low_id = true;
+    ed.name = name;
+    ed.symbol = name;
+    ecs_component_desc_t cd = {0};
+    cd.entity = ecs_entity_init(w, &ed);
+    cd.type.size = 68; /* @sizeOf */
+    cd.type.alignment = 4; /* @alignOf */
+    cd.type.hooks.on_add = on_add;
+    cd.type.hooks.on_set = any_on_set;
+    return ecs_component_init(w, &cd);
+}
+
+static ecs_entity_t make_system(ecs_world_t* w, const char* name, ecs_iter_action_t cb, int n_terms) {
+    ecs_entity_desc_t ed = {0};
+    ed.name = name;
+    ecs_system_desc_t sd = {0};
+    sd.entity = ecs_entity_init(w, &ed);
+    sd.callback = cb;
+    if (n_terms == 3) {
+        sd.query.terms[0].id = g_world_id;
+        sd.query.terms[0].inout = EcsInOut;
+        sd.query.terms[1].id = g_local_id;
+        sd.query.terms[1].inout = EcsInOut;
+        sd.query.terms[2].id = g_world_id;
+        sd.query.terms[2].inout = EcsIn;
+        sd.query.terms[2].src.id = EcsUp;
+    } else {
+        sd.query.terms[0].id = (n_terms == 1) ? g_world_id : g_local_id;
+        sd.query.terms[0].inout = EcsInOut;
+    }
+    return ecs_system_init(w, &sd);
+}
+
+#define RD(ptr, sz)                                            \
+    if (fread((ptr), 1, (sz), fin) != (size_t)(sz)) {          \
+        fprintf(stderr, "flecs_harness: short read\n");        \
+        return 2;                                              \
+    }
+
+int main(int argc, char** argv) {
+    if (argc != 3) {
+        fprintf(stderr, "usage: %s scene.bin out.bin\n", argv[0]);
+        return 2;
+    }
+    FILE* fin = fopen(argv[1], "rb");
+    FILE* fout = fopen(argv[2], "wb");
+    if (!fin || !fout) return 2;
+    char magic[4];
+    uint32_t n, n_levels, n_frames;
+    RD(magic, 4);
+    if (memcmp(magic, "YFH1", 4) != 0) return 2;
+    RD(&n, 4);
+    RD(&n_levels, 4);
+    RD(&n_frames, 4);
+    uint32_t* lo = malloc(sizeof(uint32_t) * (n_levels + 1));
+    uint32_t* parent = malloc(sizeof(uint32_t) * n);
+    float* local = malloc(sizeof(float) * 16 * (size_t)n);
+    float root_m[16];
+    RD(lo, 4 * (n_levels + 1));
+    RD(parent, 4 * (size_t)n);
+    RD(local, 64 * (size_t)n);
+    RD(root_m, 64);
+
+    ecs_world_t* w = ecs_init();
+    g_world_id = make_component(w, "WorldTransform", NULL);
+    g_local_id = make_component(w, "LocalTransform", local_on_add);
+
+    /* scene root: world.set(scene_root, WorldTransform{IDENTITY}) (GameApp.zig:95) */
+    ecs_entity_t root = ecs_new(w);
+    yo_transform68 t;
+    memset(&t, 0, sizeof t);
+    memcpy(t.matrix.v, root_m, 64);
+    ecs_set_id(w, root, g_world_id, sizeof t, &t);
+
+    ecs_entity_t* ent = malloc(sizeof(ecs_entity_t) * n);
+    for (uint32_t e = 0; e < n; ++e) { /* level-major order = parent first (GameApp.zig:204-215) */
+        const ecs_entity_t p = parent[e] == 0xFFFFFFFFu ? root : ent[parent[e]];
+        ent[e] = ecs_new_w_id(w, ecs_pair(EcsChildOf, p));
+        memset(&t, 0, sizeof t);
+        memcpy(t.matrix.v, local + 16 * (size_t)e, 64);
+        ecs_set_id(w, ent[e], g_local_id, sizeof t, &t);
+    }
+
+    const ecs_entity_t tss = make_system(w, "TransformSyncSystem", transform_sync, 3);
+    const ecs_entity_t post_w = make_system(w, "PostWorldTransform", post_clear, 1);
+    const ecs_entity_t post_l = make_system(w, "PostLocalTransform", post_clear, 2);
+
+    yo_transform68* rows = malloc(sizeof(yo_transform68) * n);
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        uint32_t n_edits;
+        RD(&n_edits, 4);
+        for (uint32_t i = 0; i < n_edits; ++i) {
+            uint32_t e, kind;
+            float m[16];
+            RD(&e, 4);
+            RD(&kind, 4);
+            RD(m, 64);
+            const ecs_entity_t target = e == 0xFFFFFFFFu ? root : ent[e];
+            const ecs_entity_t comp = kind == 0 ? g_local_id : g_world_id;
+            yo_transform68* p = (yo_transform68*)ecs_ensure_id(w, target, comp);
+            memcpy(p->matrix.v, m, 64);
+            ecs_modified_id(w, target, comp); /* -> onSet -> dirty */
+        }
+        g_batches = g_rows = 0;
+        /* PostUpdate: TransformSyncSystem, then its two dependents (ecs.zig:277-293) */
+        ecs_run(w, tss, 0.016f, NULL);
+        ecs_run(w, post_w, 0.016f, NULL);
+        ecs_run(w, post_l, 0.016f, NULL);
+        for (int comp = 0; comp < 2; ++comp) {
+            for (uint32_t e = 0; e < n; ++e) {
+                const yo_transform68* p = (const yo_transform68*)ecs_get_id(w, ent[e], comp == 0 ? g_world_id : g_local_id);
+                rows[e] = *p;
+                rows[e].pad[0] = rows[e].pad[1] = rows[e].pad[2] = 0;
+            }
+            fwrite(rows, sizeof(yo_transform68), n, fout);
+        }
+        fwrite(&g_batches, 8, 1, fout);
+        fwrite(&g_rows, 8, 1, fout);
+        fwrite(&g_up_shared, 4, 1, fout);
+    }
+    fclose(fout);
+    fclose(fin);
+    ecs_fini(w);
+    return 0;
+}
