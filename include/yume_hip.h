@@ -194,6 +194,19 @@ int yh_download_trs(yh_scene* s, float* const planes[10], uint64_t first, uint64
 int yh_download_aabb(yh_scene* s, float* const min_planes[3], float* const max_planes[3], uint64_t first,
                      uint64_t count);
 
+/* ---- sharding (host only) ------------------------------------------------------------------ */
+/* Subtree-closed partition of a depth-sorted hierarchy over n_parts GPUs: every level-0 entity's whole subtree
+ * goes to one part (greedy largest-first bin packing on subtree sizes), so no parent is ever read across GPUs.
+ * part_of_entity: n entries; part_sizes: n_parts entries.  Replaces nothing in the reference (single process).  */
+int yh_partition_subtrees(const uint32_t* parent_index, const uint32_t* level_offsets, uint32_t n_levels,
+                          uint32_t n_parts, uint32_t* part_of_entity, uint64_t* part_sizes);
+/* Builds shard `part`: its own depth-sorted arrays (level-major, sibling order kept, parents re-indexed) and the
+ * map back to global slots.  local_parent / global_of_local: part_sizes[part] entries; local_level_offsets:
+ * n_levels + 1.                                                                                          */
+int yh_shard_extract(const uint32_t* parent_index, const uint32_t* level_offsets, uint32_t n_levels,
+                     const uint32_t* part_of_entity, uint32_t part, uint32_t* local_parent,
+                     uint32_t* local_level_offsets, uint32_t* global_of_local);
+
 /* ---- multi-GPU (one process per GPU; RCCL over xGMI) --------------------------------------------------- */
 #define YH_UNIQUE_ID_BYTES 128
 int yh_comm_unique_id(void* out_id /* YH_UNIQUE_ID_BYTES */);

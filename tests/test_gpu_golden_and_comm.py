@@ -1,0 +1,67 @@
+"""GPU tests against the committed golden fixtures (tests/golden/*.npz) and of the RCCL entry points with a
+one-rank communicator (the only RCCL configuration a one-GPU box can run; the N > 1 logic is covered on CPU
+by tests/test_sharding.py and at round end by the driver's multi-GPU bench)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name", ["cfg1_flat10k", "tree4096_l8", "frusta5_flat4096"])
+def test_gpu_matches_golden_fixture(ctx, oracle, name):
+    from tests.golden.make_golden import scene_for
+    from yume_amd import Scene
+
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sc = scene_for(oracle, name)  # inputs are regenerated from the seed; expected outputs come from the fixture
+    F = sc["planes"].shape[0]
+    with Scene(ctx, sc["n"], n_levels=len(sc["level_offsets"]) - 1, n_frusta=F) as s:
+        s.upload_hierarchy(sc["parent"], sc["level_offsets"])
+        s.upload_trs(sc["trs"])
+        s.upload_aabb(np.ascontiguousarray(sc["bounds"][:, :3].T), np.ascontiguousarray(sc["bounds"][:, 3:].T))
+        s.frame(sc["planes"])
+        assert np.array_equal(s.world_soa().T, g["world"])  # values equal (the fixture holds no NaN)
+        counts, bcounts = s.counts()
+        for f in range(F):
+            assert np.array_equal(s.draw_list(f), g[f"vis{f}"]), f"frustum {f}"
+            assert counts[f] == g[f"vis{f}"].size and bcounts[f] == g[f"bnd{f}"].size
+
+
+def test_rccl_one_rank_allgather(oracle):
+    from yume_amd import Context, Scene
+
+    n = 200_000
+    lo = oracle.synth_level_offsets(n, 5)
+    par = oracle.synth_parents(lo)
+    planes = np.concatenate([oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()[:1]])
+    with Context(0) as c:
+        c.comm_init(1, 0, Context.comm_unique_id())
+        with Scene(c, n, n_levels=5, n_frusta=2, id_base=7_000_000) as s:
+            s.upload_hierarchy(par, lo)
+            s.fill_synthetic()
+            s.frame(planes)
+            counts, _ = s.counts()
+            all_counts = s.allgather_draw_lists()
+            assert all_counts.shape == (1, 2) and np.array_equal(all_counts[0], counts[:2])
+            for f in range(2):
+                local = s.draw_list(f)
+                gathered = s.gathered_draw_list(f, all_counts[:, f].sum())
+                assert np.array_equal(gathered, local) and (local.size == 0 or local.min() >= 7_000_000)
+            # a second frame + gather reuses the buffers
+            s.frame(planes)
+            assert np.array_equal(s.allgather_draw_lists()[0], counts[:2])
+
+
+def test_allgather_without_communicator_is_a_state_error(ctx, oracle):
+    from yume_amd import Scene, _lib
+
+    with Scene(ctx, 1000, n_frusta=1) as s:
+        s.upload_flat()
+        s.fill_synthetic()
+        s.frame(oracle.main_camera_planes())
+        with pytest.raises(_lib.YumeHipError) as e:
+            s.allgather_draw_lists()
+        assert e.value.code == _lib.YH_ERR_STATE

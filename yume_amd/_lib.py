@@ -115,6 +115,8 @@ SIGNATURES = {
     "yh_scene_fill_synthetic": (_int, [_vp, C.POINTER(SynthDesc)]),
     "yh_download_trs": (_int, [_vp, _vp, _u64, _u64]),
     "yh_download_aabb": (_int, [_vp, _vp, _vp, _u64, _u64]),
+    "yh_partition_subtrees": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    "yh_shard_extract": (_int, [_vp, _vp, _u32, _vp, _u32, _vp, _vp, _vp]),
     "yh_comm_unique_id": (_int, [_vp]),
     "yh_comm_init": (_int, [_vp, _int, _int, _vp]),
     "yh_comm_destroy": (None, [_vp]),

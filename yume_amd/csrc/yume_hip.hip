@@ -1020,6 +1020,69 @@ extern "C" int yh_scene_fill_synthetic(yh_scene* s, const yh_synth_desc* d) {
     return sync_scene(s);
 }
 
+// ------------------------------------------------------------------------------------------- sharding
+extern "C" int yh_partition_subtrees(const uint32_t* parent, const uint32_t* lo, uint32_t n_levels, uint32_t n_parts,
+                                     uint32_t* part_of, uint64_t* part_sizes) {
+    if (!parent || !lo || !part_of || !part_sizes) return fail(nullptr, YH_ERR_BAD_ARG, "yh_partition_subtrees: NULL argument");
+    if (n_levels < 1 || n_levels > YH_MAX_LEVELS || n_parts < 1) return fail(nullptr, YH_ERR_BAD_ARG, "yh_partition_subtrees: bad n_levels / n_parts");
+    const uint32_t n = lo[n_levels], n0 = lo[1];
+    // root_of[e] = level-0 ancestor; parents precede children, so one forward sweep is enough
+    std::vector<uint32_t> root_of(n);
+    std::vector<uint64_t> subtree(n0, 0);
+    for (uint32_t e = 0; e < n0; ++e) root_of[e] = e;
+    for (uint32_t k = 1; k < n_levels; ++k)
+        for (uint32_t e = lo[k]; e < lo[k + 1]; ++e) {
+            const uint32_t p = parent[e];
+            if (p < lo[k - 1] || p >= lo[k]) return fail(nullptr, YH_ERR_BAD_ARG, "yh_partition_subtrees: entity %u has a parent outside the previous level", e);
+            root_of[e] = root_of[p];
+        }
+    for (uint32_t e = 0; e < n; ++e) subtree[root_of[e]]++;
+    // greedy largest-first bin packing (ties: lower slot first, so the result is deterministic)
+    std::vector<uint32_t> order(n0);
+    for (uint32_t i = 0; i < n0; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return subtree[a] > subtree[b]; });
+    std::vector<uint64_t> load(n_parts, 0);
+    std::vector<uint32_t> part_of_root(n0);
+    for (uint32_t r : order) {
+        uint32_t best = 0;
+        for (uint32_t p = 1; p < n_parts; ++p)
+            if (load[p] < load[best]) best = p;
+        part_of_root[r] = best;
+        load[best] += subtree[r];
+    }
+    for (uint32_t e = 0; e < n; ++e) part_of[e] = part_of_root[root_of[e]];
+    for (uint32_t p = 0; p < n_parts; ++p) part_sizes[p] = load[p];
+    return YH_OK;
+}
+
+extern "C" int yh_shard_extract(const uint32_t* parent, const uint32_t* lo, uint32_t n_levels, const uint32_t* part_of,
+                                uint32_t part, uint32_t* local_parent, uint32_t* local_lo, uint32_t* global_of_local) {
+    if (!parent || !lo || !part_of || !local_parent || !local_lo || !global_of_local)
+        return fail(nullptr, YH_ERR_BAD_ARG, "yh_shard_extract: NULL argument");
+    if (n_levels < 1 || n_levels > YH_MAX_LEVELS) return fail(nullptr, YH_ERR_BAD_ARG, "yh_shard_extract: bad n_levels");
+    const uint32_t n = lo[n_levels];
+    std::vector<uint32_t> local_of(n, YH_NO_PARENT);
+    uint32_t next = 0;
+    local_lo[0] = 0;
+    for (uint32_t k = 0; k < n_levels; ++k) {
+        for (uint32_t e = lo[k]; e < lo[k + 1]; ++e) {
+            if (part_of[e] != part) continue;
+            local_of[e] = next;
+            global_of_local[next] = e;
+            if (k == 0) {
+                local_parent[next] = YH_NO_PARENT;
+            } else {
+                const uint32_t lp = local_of[parent[e]];
+                if (lp == YH_NO_PARENT) return fail(nullptr, YH_ERR_BAD_ARG, "yh_shard_extract: entity %u and its parent are in different parts", e);
+                local_parent[next] = lp;  // global sibling order is kept, so siblings stay sorted by parent
+            }
+            ++next;
+        }
+        local_lo[k + 1] = next;
+    }
+    return YH_OK;
+}
+
 // -------------------------------------------------------------------------------------------- RCCL
 // RCCL is loaded on demand so that single-GPU users never depend on it.  Types are kept opaque; the
 // enum values below are RCCL's (rccl.h: ncclUint32 = 3, ncclSuccess = 0).
