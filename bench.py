@@ -171,16 +171,36 @@ def main():
     flags = _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC
 
     collective = "none"
+    use_lib_comm = True
     if world_size > 1:
-        ids = [Context.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.comm_init(world_size, rank, ids[0])
-        collective = "rccl allgather(counts) + grouped bcast(lists), direct"
+        # product path: the library's own RCCL communicator (ncclAllGather of counts + grouped ncclBroadcast of the
+        # exact-size lists on the library's stream).  If it cannot be brought up on every rank, stand by with
+        # torch.distributed ("nccl" = RCCL as well) over downloaded lists and say so in the report.
+        err = ""
+        try:
+            ids = [Context.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            ctx.comm_init(world_size, rank, ids[0])
+            scene.frame(planes, _lib.YH_FRAME_ALL_DIRTY)
+            scene.allgather_draw_lists()
+            ok = 1
+        except Exception as ex:  # noqa: BLE001
+            ok, err = 0, str(ex)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        use_lib_comm = bool(flag.item())
+        collective = ("rccl (library): allgather(counts) + grouped bcast(exact-size lists)" if use_lib_comm
+                      else f"torch.distributed nccl stand-by (library communicator failed: {err[:120]})")
 
     def step():
         scene.frame(planes, flags)
         if world_size > 1:
-            scene.allgather_draw_lists()
+            if use_lib_comm:
+                scene.allgather_draw_lists()
+            else:
+                from yume_amd import shard
+
+                shard.allgather_draw_lists_torch([scene.draw_list(f) for f in range(F)], device="cuda")
 
     def barrier():
         ctx.wait()
@@ -256,7 +276,7 @@ def main():
     for _ in range(min(50, args.steps)):
         a = time.perf_counter()
         scene.frame(planes, _lib.YH_FRAME_ALL_DIRTY)
-        if world_size > 1:
+        if world_size > 1 and use_lib_comm:
             scene.allgather_draw_lists()
         lat.append(time.perf_counter() - a)
 

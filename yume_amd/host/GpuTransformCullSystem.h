@@ -1,0 +1,59 @@
+/*
+ * GpuTransformCullSystem — engine-side system that replaces TransformSyncSystem + PostTransformSystem with the
+ * MI355X path, written against the flecs C API the engine's ecs.zig wraps.
+ *
+ * Mirrors the reference's registration interface:
+ *     engine/systems/TransformSyncSystem.zig:12   pub fn registerTo(world: ecs.World) ecs.Entity
+ *     engine/systems/PostTransformSystem.zig:12   pub fn registerTo(world, scope, transform_sync_sys) ecs.Entity
+ *     editor/Editor.zig:153-162                   the call site (register, then tag the returned entity)
+ * Same contract: creates a system entity named "GpuTransformCullSystem" in phase PostUpdate over the same three
+ * query terms (WorldTransform inout, LocalTransform inout, WorldTransform in src=Up) and returns it; the dirty reset
+ * happens inside the same system, so the two PostTransform systems are not registered when this one is.
+ * It uses SystemDesc.run (ecs.zig:1209), i.e. it walks all matched tables once per frame instead of being called
+ * per table: columns (ecs.field, ecs.zig:695-705) are copied into one depth-sorted staging column, sent through
+ * yh_upload_*_aos68 -> yh_frame -> yh_download_*_aos68, and copied back, so every CPU reader of
+ * WorldTransform.matrix (RenderApi.zig:1398-1402, SceneWindow.zig:334-351) keeps working.
+ *
+ * The Zig twin of this file is zig/engine/systems/GpuTransformCullSystem.zig.
+ */
+#ifndef YUME_GPU_TRANSFORM_CULL_SYSTEM_H
+#define YUME_GPU_TRANSFORM_CULL_SYSTEM_H
+
+#include "flecs.h"
+#include "yume_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct GpuTransformCullSystem GpuTransformCullSystem;
+
+/* registerTo(world): local_transform / world_transform are the component ids (ecs.typeId(T), ecs.zig:691-693).
+ * The context is created by the caller (yh_init) and outlives the system.  Returns the system entity, 0 on error
+ * (yh_last_error(ctx) tells why).  *out_state receives the system's state for the calls below. */
+ecs_entity_t GpuTransformCullSystem_registerTo(ecs_world_t* world, ecs_entity_t local_transform,
+                                               ecs_entity_t world_transform, yh_ctx* ctx,
+                                               GpuTransformCullSystem** out_state);
+
+/* Local-space bounds of an entity's mesh (engine/meshes.zig:72-95); entities without one get an empty box at the
+ * origin.  min_max: 6 floats.  Takes effect at the next frame. */
+int GpuTransformCullSystem_setBounds(GpuTransformCullSystem* s, ecs_entity_t entity, const float min_max[6]);
+
+/* Frusta of the next frames: n x 24 floats (yh_extract_planes of Camera.view_projection, camera.zig:300-302). */
+int GpuTransformCullSystem_setFrusta(GpuTransformCullSystem* s, const float* planes, uint32_t n_frusta);
+
+/* Visible entities of the last frame for one frustum, ascending slot order.  Returns the count; writes at most cap. */
+uint64_t GpuTransformCullSystem_visible(GpuTransformCullSystem* s, uint32_t frustum, ecs_entity_t* out, uint64_t cap);
+
+/* Last error code of the per-frame run (0 = ok): system callbacks cannot return one. */
+int GpuTransformCullSystem_status(const GpuTransformCullSystem* s);
+uint64_t GpuTransformCullSystem_entities(const GpuTransformCullSystem* s);
+uint32_t GpuTransformCullSystem_levels(const GpuTransformCullSystem* s);
+uint64_t GpuTransformCullSystem_rebuilds(const GpuTransformCullSystem* s);
+
+void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
