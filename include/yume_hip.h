@@ -85,7 +85,7 @@ typedef struct yh_scene_desc {
                                      the only mode of YH_LOCAL_TRS scenes)                                   */
 #define YH_FRAME_NO_CULL     0x2u /* skip stage 3 */
 #define YH_FRAME_ASYNC       0x4u /* enqueue only; yh_wait() or any yh_get_ / yh_download_ call synchronises */
-#define YH_FRAME_ORDERED     0x8u /* draw lists in ascending entity order (two-pass scan instead of atomics) */
+#define YH_FRAME_ORDERED     0x8u /* accepted, no effect: draw lists are ALWAYS in ascending entity order        */
 
 typedef struct yh_timing {
     float last_frame_ms;    /* device time of the most recent frame (hipEvent; 0 unless kernel timing is on) */
@@ -123,6 +123,9 @@ void yh_scene_destroy(yh_scene* scene);
 int yh_upload_hierarchy(yh_scene* s, const uint32_t* parent_index, const uint32_t* level_offsets);
 /* WorldTransform of the scene root (GameApp.zig:95); identity until set. */
 int yh_set_root(yh_scene* s, const float root_world[16]);
+/* The same from the root's 68-byte WorldTransform row as the `Up` term hands it to level-0 tables
+ * (TransformSyncSystem.zig:34-36, 47): matrix AND the row's own dirty byte, nothing implied.             */
+int yh_upload_root_aos68(yh_scene* s, const void* row);
 
 /* Stage-1 inputs: SoA TRS planes, order tx,ty,tz,qx,qy,qz,qw,sx,sy,sz (Mat4.compose arguments,
  * math3d.zig:816).  Entities [first, first+count).                                                       */

@@ -14,11 +14,21 @@
  * this binary pins is the ECS side: which rows flecs batches together, that the `Up` field is ONE shared value
  * per batch, parent-first table order (F5), and dirty-flag propagation across frames.
  *
+ * Built twice by oracle/Makefile: as is (the reference's three CPU systems), and with -DUSE_GPU_SYSTEM, where the
+ * SAME world, components, hooks, scene and edits are driven through yume_amd/host/GpuTransformCullSystem.c instead
+ * (binary flecs_gpu_harness, needs a GPU).  tests/test_gpu_flecs_system.py compares the two outputs byte for byte.
+ *
  * usage: flecs_harness <scene.bin> <out.bin>
- * scene.bin: "YFH1" u32 n, n_levels, n_frames | u32 level_offsets[n_levels+1] | u32 parent[n] | f32 local[n][16]
- *            | f32 root[16] | per frame: u32 n_edits, then {u32 entity (0xFFFFFFFF = root), u32 kind (0 = local,
- *            1 = world), f32 m[16]} applied before the frame as set + modified (editor/editors/transform.zig:76-79)
- * out.bin:   per frame: world rows n x 68 B, local rows n x 68 B, u64 batches, u64 rows_seen, u32 up_fields_shared
+ * scene.bin: "YFH1"|"YFH2" u32 n, n_levels, n_frames | u32 level_offsets[n_levels+1] | u32 parent[n]
+ *            | f32 local[n][16] | f32 root[16]
+ *            | YFH2 only: u32 n_frusta, f32 planes[n_frusta][24], f32 bounds[n][6] (min.xyz, max.xyz)
+ *            | per frame: u32 n_edits, then {u32 entity (0xFFFFFFFF = root), u32 kind, f32 m[16]} applied before the
+ *              frame.  kind 0 / 1: set + modified of the local / world matrix (editor/editors/transform.zig:76-79);
+ *              kind 2: delete the entity (children go with it, flecs' ChildOf cleanup);
+ *              kind 3: re-parent under entity index bits(m[0]) (ecs.zig:470-477 setParent)
+ * out.bin:   per frame: world rows n x 68 B, local rows n x 68 B (all zero for deleted entities), u64 batches,
+ *            u64 rows_seen, u32 up_fields_shared; GPU build + YFH2: then per frustum u32 count, u32 entity_index[count]
+ *            (GPU build: batches = slot-order rebuilds so far, rows_seen = entities in the device scene)
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -27,6 +37,9 @@
 
 #include "flecs.h"
 #include "yume_oracle.h"
+#ifdef USE_GPU_SYSTEM
+#include "GpuTransformCullSystem.h"
+#endif
 
 static ecs_entity_t g_local_id, g_world_id;
 static uint64_t g_batches, g_rows;
@@ -117,7 +130,8 @@ int main(int argc, char** argv) {
     char magic[4];
     uint32_t n, n_levels, n_frames;
     RD(magic, 4);
-    if (memcmp(magic, "YFH1", 4) != 0) return 2;
+    const int v2 = memcmp(magic, "YFH2", 4) == 0;
+    if (!v2 && memcmp(magic, "YFH1", 4) != 0) return 2;
     RD(&n, 4);
     RD(&n_levels, 4);
     RD(&n_frames, 4);
@@ -129,6 +143,16 @@ int main(int argc, char** argv) {
     RD(parent, 4 * (size_t)n);
     RD(local, 64 * (size_t)n);
     RD(root_m, 64);
+    uint32_t n_frusta = 0;
+    float planes[8 * 24];
+    float* bounds = NULL;
+    if (v2) {
+        RD(&n_frusta, 4);
+        if (n_frusta > 8) return 2;
+        RD(planes, 96 * n_frusta);
+        bounds = malloc(sizeof(float) * 6 * (size_t)n);
+        RD(bounds, 24 * (size_t)n);
+    }
 
     ecs_world_t* w = ecs_init();
     g_world_id = make_component(w, "WorldTransform", NULL);
@@ -150,9 +174,27 @@ int main(int argc, char** argv) {
         ecs_set_id(w, ent[e], g_local_id, sizeof t, &t);
     }
 
+#ifdef USE_GPU_SYSTEM
+    yh_ctx* ctx = NULL;
+    if (yh_init(0, &ctx) != YH_OK) {
+        fprintf(stderr, "flecs_gpu_harness: yh_init: %s\n", yh_last_error(NULL));
+        return 3;
+    }
+    GpuTransformCullSystem* gpu = NULL;
+    const ecs_entity_t gsys = GpuTransformCullSystem_registerTo(w, g_local_id, g_world_id, ctx, &gpu);
+    if (!gsys) return 3;
+    if (v2) {
+        for (uint32_t e = 0; e < n; ++e) GpuTransformCullSystem_setBounds(gpu, ent[e], bounds + 6 * (size_t)e);
+        GpuTransformCullSystem_setFrusta(gpu, planes, n_frusta);
+    }
+    ecs_entity_t* vis = malloc(sizeof(ecs_entity_t) * n);
+    uint32_t* vis_idx = malloc(sizeof(uint32_t) * n);
+#else
+    (void)planes;
     const ecs_entity_t tss = make_system(w, "TransformSyncSystem", transform_sync, 3);
     const ecs_entity_t post_w = make_system(w, "PostWorldTransform", post_clear, 1);
     const ecs_entity_t post_l = make_system(w, "PostLocalTransform", post_clear, 2);
+#endif
 
     yo_transform68* rows = malloc(sizeof(yo_transform68) * n);
     for (uint32_t f = 0; f < n_frames; ++f) {
@@ -165,6 +207,16 @@ int main(int argc, char** argv) {
             RD(&kind, 4);
             RD(m, 64);
             const ecs_entity_t target = e == 0xFFFFFFFFu ? root : ent[e];
+            if (kind == 2) {
+                ecs_delete(w, target);
+                continue;
+            }
+            if (kind == 3) {
+                uint32_t np;
+                memcpy(&np, m, 4);
+                ecs_add_id(w, target, ecs_pair(EcsChildOf, np == 0xFFFFFFFFu ? root : ent[np]));
+                continue;
+            }
             const ecs_entity_t comp = kind == 0 ? g_local_id : g_world_id;
             yo_transform68* p = (yo_transform68*)ecs_ensure_id(w, target, comp);
             memcpy(p->matrix.v, m, 64);
@@ -172,11 +224,24 @@ int main(int argc, char** argv) {
         }
         g_batches = g_rows = 0;
         /* PostUpdate: TransformSyncSystem, then its two dependents (ecs.zig:277-293) */
+#ifdef USE_GPU_SYSTEM
+        ecs_run(w, gsys, 0.016f, NULL);
+        if (GpuTransformCullSystem_status(gpu) != YH_OK) {
+            fprintf(stderr, "flecs_gpu_harness: frame %u: status %d: %s\n", f, GpuTransformCullSystem_status(gpu),
+                    yh_last_error(ctx));
+            return 4;
+        }
+        g_batches = GpuTransformCullSystem_rebuilds(gpu);
+        g_rows = GpuTransformCullSystem_entities(gpu);
+#else
         ecs_run(w, tss, 0.016f, NULL);
         ecs_run(w, post_w, 0.016f, NULL);
         ecs_run(w, post_l, 0.016f, NULL);
+#endif
         for (int comp = 0; comp < 2; ++comp) {
             for (uint32_t e = 0; e < n; ++e) {
+                memset(&rows[e], 0, sizeof rows[e]);
+                if (!ecs_is_alive(w, ent[e])) continue;
                 const yo_transform68* p = (const yo_transform68*)ecs_get_id(w, ent[e], comp == 0 ? g_world_id : g_local_id);
                 rows[e] = *p;
                 rows[e].pad[0] = rows[e].pad[1] = rows[e].pad[2] = 0;
@@ -186,7 +251,28 @@ int main(int argc, char** argv) {
         fwrite(&g_batches, 8, 1, fout);
         fwrite(&g_rows, 8, 1, fout);
         fwrite(&g_up_shared, 4, 1, fout);
+#ifdef USE_GPU_SYSTEM
+        for (uint32_t fr = 0; fr < n_frusta; ++fr) {
+            const uint64_t cnt = GpuTransformCullSystem_visible(gpu, fr, vis, n);
+            for (uint64_t i = 0; i < cnt; ++i) { /* entity ids grow with the creation index: binary search */
+                uint32_t lo_i = 0, hi_i = n - 1;
+                while (lo_i < hi_i) {
+                    const uint32_t mid = (lo_i + hi_i) / 2;
+                    if (ent[mid] < vis[i]) lo_i = mid + 1;
+                    else hi_i = mid;
+                }
+                vis_idx[i] = lo_i;
+            }
+            const uint32_t c32 = (uint32_t)cnt;
+            fwrite(&c32, 4, 1, fout);
+            fwrite(vis_idx, 4, c32, fout);
+        }
+#endif
     }
+#ifdef USE_GPU_SYSTEM
+    GpuTransformCullSystem_destroy(gpu);
+    yh_shutdown(ctx);
+#endif
     fclose(fout);
     fclose(fin);
     ecs_fini(w);

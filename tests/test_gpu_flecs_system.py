@@ -1,0 +1,125 @@
+"""The engine-side drop-in, end to end: the REAL flecs 4.0.4 world (the reference's vendored copy, compiled in place
+into oracle/_ref/) with yume_amd/host/GpuTransformCullSystem.c registered instead of TransformSyncSystem +
+PostTransformSystem must leave every WorldTransform / LocalTransform row — matrices and dirty bytes — exactly as the
+reference's three CPU systems leave them, frame after frame, through local edits, world-only edits (inverse branch),
+a singular matrix, a re-rooting, deletions and a re-parenting (slot-order rebuilds).  Both binaries are built from
+oracle/flecs_harness.c by `make -C oracle ref`; the visible lists of the GPU run are checked against the oracle's
+culling of the CPU run's world matrices."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPU = os.path.join(ROOT, "oracle", "_ref", "flecs_harness")
+GPU = os.path.join(ROOT, "oracle", "_ref", "flecs_gpu_harness")
+
+pytestmark = [
+    pytest.mark.gpu,
+    pytest.mark.skipif(not (os.path.exists(CPU) and os.path.exists(GPU)), reason="oracle/_ref harnesses not built"),
+]
+
+
+def write_scene(path, lo, parent, local_m, root_m, planes, bounds, frames):
+    n = parent.shape[0]
+    with open(path, "wb") as f:
+        f.write(b"YFH2")
+        f.write(struct.pack("<III", n, len(lo) - 1, len(frames)))
+        f.write(np.ascontiguousarray(lo, np.uint32).tobytes())
+        f.write(np.ascontiguousarray(parent, np.uint32).tobytes())
+        f.write(np.ascontiguousarray(local_m, np.float32).tobytes())
+        f.write(np.ascontiguousarray(root_m, np.float32).tobytes())
+        f.write(struct.pack("<I", planes.shape[0]))
+        f.write(np.ascontiguousarray(planes, np.float32).tobytes())
+        f.write(np.ascontiguousarray(bounds, np.float32).tobytes())
+        for edits in frames:
+            f.write(struct.pack("<I", len(edits)))
+            for e, kind, m in edits:
+                f.write(struct.pack("<II", 0xFFFFFFFF if e < 0 else e, kind))
+                f.write(np.ascontiguousarray(m, np.float32).tobytes())
+
+
+def read_out(path, n, n_frames, n_frusta, T68):
+    raw = open(path, "rb").read()
+    res, pos = [], 0
+    for _ in range(n_frames):
+        w = np.frombuffer(raw, T68, n, pos).copy()
+        pos += 68 * n
+        l = np.frombuffer(raw, T68, n, pos).copy()
+        pos += 68 * n
+        a, b, shared = struct.unpack_from("<QQI", raw, pos)
+        pos += 20
+        vis = []
+        for _f in range(n_frusta):
+            (c,) = struct.unpack_from("<I", raw, pos)
+            vis.append(np.frombuffer(raw, np.uint32, c, pos + 4).copy())
+            pos += 4 + 4 * c
+        res.append((w, l, a, b, vis))
+    assert pos == len(raw)
+    return res
+
+
+def reparent_arg(index):
+    m = np.zeros(16, np.float32)
+    m.view(np.uint32)[0] = index
+    return m
+
+
+@pytest.mark.parametrize("n,levels", [(10_000, 1), (4096, 8), (50_000, 6)])
+def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, levels):
+    rng = np.random.default_rng(n + levels)
+    lo = oracle.synth_level_offsets(n, levels)
+    par = oracle.synth_parents(lo)
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo[1])))
+    bounds = oracle.synth_aabb(n)
+    planes = np.concatenate([oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()[:2]])
+
+    def rnd_m(scale=5.0):
+        return oracle.compose(rng.uniform(-scale, scale, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+
+    frames = [[], []]
+    frames.append([(int(e), 0, rnd_m()) for e in np.unique(rng.integers(0, n, 300))])
+    frames.append([(int(e), 1, rnd_m(50.0)) for e in np.unique(rng.integers(0, n, 200))])
+    frames.append([(int(rng.integers(0, int(lo[1]))), 0, np.zeros(16, np.float32))])
+    frames.append([(-1, 1, oracle.compose([1, 2, 3], [0, 0.7071068, 0, 0.7071068], [2, 2, 2]))])
+    # structural changes: delete a few last-level entities (no children), re-parent a few others one level up or to
+    # another parent of the same level (leaves only, so flecs' table order stays parent-first: SURVEY F5)
+    last = np.arange(int(lo[-2]), n)
+    doomed = rng.choice(last, 20, replace=False)
+    frames.append([(int(e), 2, np.zeros(16, np.float32)) for e in doomed])
+    movers = np.setdiff1d(last, doomed)[:10]
+    if levels > 1:
+        new_par = rng.integers(int(lo[-3]), int(lo[-2]), movers.size)
+        frames.append([(int(e), 3, reparent_arg(int(p))) for e, p in zip(movers, new_par)] + [(int(movers[0]), 0, rnd_m())])
+    else:
+        frames.append([(int(movers[0]), 0, rnd_m())])
+    frames.append([])
+
+    scene, out_c, out_g = tmp_path / "scene.bin", tmp_path / "cpu.bin", tmp_path / "gpu.bin"
+    write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
+    subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
+    subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300)
+    cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
+    gpu = read_out(out_g, n, len(frames), planes.shape[0], oracle.T68)
+
+    alive = np.ones(n, bool)
+    rebuilds_before = 0
+    for fi, ((cw, cl, _, rows, _), (gw, gl, rebuilds, g_rows, vis)) in enumerate(zip(cpu, gpu)):
+        for e, kind, _m in frames[fi]:
+            if kind == 2:
+                alive[e] = False
+        with np.errstate(all="ignore"):
+            # IEEE value equality; the only representation freedom is the sign of a zero (compose/mul)
+            assert np.array_equal(gw["m"], cw["m"], equal_nan=True), f"frame {fi}: world matrices"
+            assert np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi}: local matrices"
+        assert np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"]), f"frame {fi}: dirty bytes"
+        assert g_rows == rows == alive.sum()
+        structural = any(kind in (2, 3) for _e, kind, _m in frames[fi])
+        assert rebuilds == rebuilds_before + (1 if (fi == 0 or structural) else 0), f"frame {fi}: rebuild count"
+        rebuilds_before = rebuilds
+        idx = np.flatnonzero(alive)
+        exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[idx]), np.ascontiguousarray(bounds[idx]), planes)
+        for f in range(planes.shape[0]):
+            assert np.array_equal(np.sort(vis[f]), idx[np.flatnonzero(exp_vis[f])]), f"frame {fi} frustum {f}: visible set"

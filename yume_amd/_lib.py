@@ -88,6 +88,7 @@ SIGNATURES = {
     "yh_scene_destroy": (None, [_vp]),
     "yh_upload_hierarchy": (_int, [_vp, _vp, _vp]),
     "yh_set_root": (_int, [_vp, _vp]),
+    "yh_upload_root_aos68": (_int, [_vp, _vp]),
     "yh_upload_trs": (_int, [_vp, _vp, _u64, _u64]),
     "yh_upload_local_aos68": (_int, [_vp, _vp, _u64, _u64]),
     "yh_upload_world_aos68": (_int, [_vp, _vp, _u64, _u64]),

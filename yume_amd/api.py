@@ -129,6 +129,11 @@ class Scene:
         m = np.ascontiguousarray(m, np.float32).reshape(16)
         self._ck(L.lib().yh_set_root(self._h, _ptr(m)))
 
+    def upload_root_aos68(self, row):
+        """Root WorldTransform as a 68-byte row: matrix and the row's own dirty byte."""
+        row = np.ascontiguousarray(row).view(np.uint8).reshape(68)
+        self._ck(L.lib().yh_upload_root_aos68(self._h, _ptr(row)))
+
     def upload_trs(self, trs, first=0):
         trs = np.ascontiguousarray(trs, np.float32)
         assert trs.shape[0] == 10

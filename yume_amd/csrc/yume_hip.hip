@@ -368,6 +368,13 @@ extern "C" int yh_set_root(yh_scene* s, const float root_world[16]) {
     return YH_OK;
 }
 
+extern "C" int yh_upload_root_aos68(yh_scene* s, const void* row) {
+    if (!s || !row) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_upload_root_aos68: NULL argument");
+    memcpy(s->root, row, sizeof s->root);
+    s->root_dirty = static_cast<const uint8_t*>(row)[64] != 0;  // the row's own flag: no onSet implied
+    return YH_OK;
+}
+
 static int ensure_staging(yh_scene* s, uint64_t bytes);
 
 // elements per staging pass of plane uploads / downloads
@@ -646,7 +653,6 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_frame: scene is NULL");
     yh_ctx* ctx = s->ctx;
     if (!s->have_hierarchy) return fail(ctx, YH_ERR_STATE, "yh_frame: call yh_upload_hierarchy first");
-    if (flags & YH_FRAME_ORDERED) return fail(ctx, YH_ERR_UNSUPPORTED, "yh_frame: YH_FRAME_ORDERED is not implemented yet");
     const bool cull = !(flags & YH_FRAME_NO_CULL) && s->desc.bounds_kind != YH_BOUNDS_NONE && n_frusta > 0;
     if (cull) {
         ARG_TRY(ctx, planes, "yh_frame: planes is NULL");

@@ -1,0 +1,552 @@
+/*
+ * GpuTransformCullSystem.c — see GpuTransformCullSystem.h.  Plain C against the flecs C API and the yume_hip C ABI.
+ *
+ * Per frame (one call of the `run` callback, SystemDesc.run — ecs.zig:1209):
+ *   1. walk every matched table once (ecs_iter_next) and note its columns, row count and the source entity of the
+ *      `Up` term (ONE parent per table: ChildOf is part of the archetype);
+ *   2. if the walk differs from the last one (entities created / deleted / re-parented), rebuild the depth-sorted
+ *      slot order: a table's level is its parent's level + 1, tables whose parent is not itself matched (the scene
+ *      root, GameApp.zig:77,95) are level 0; tables of one level are ordered by their parent's slot, which makes
+ *      siblings contiguous and sorted by parent, as yh_upload_hierarchy wants (A10);
+ *   3. copy both 68-byte columns of every table into slot order, yh_upload_*_aos68, yh_frame, yh_download_*_aos68,
+ *      copy back.  The frame applies the three-branch rule (TransformSyncSystem.zig:53-74) level by level and then
+ *      clears every dirty flag (PostTransformSystem.zig:27-37), the root's included.
+ *
+ * Difference from the CPU systems worth knowing: the reference visits tables in flecs' storage order and
+ * is parent-first only when entities were created parent-first; a child table stored before its parent's table reads
+ * last frame's parent matrix there.  This system always runs parents first.
+ */
+#include "GpuTransformCullSystem.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define ROW 68u
+
+typedef struct Batch {
+    void* world_col;
+    void* local_col;
+    void* up_row; /* the shared parent row the Up term resolved to */
+    ecs_entity_t src; /* entity the Up term was matched on */
+    uint32_t count;
+    uint32_t walk_begin; /* first row in walk order */
+    uint32_t slot_begin; /* first row in slot order */
+    int32_t level;
+} Batch;
+
+typedef struct MapEntry {
+    ecs_entity_t key; /* 0 = empty */
+    uint32_t value;
+} MapEntry;
+
+typedef struct Map {
+    MapEntry* e;
+    uint64_t cap; /* power of two */
+} Map;
+
+typedef struct BoundsEntry {
+    ecs_entity_t key;
+    float mm[6];
+} BoundsEntry;
+
+struct GpuTransformCullSystem {
+    ecs_world_t* world;
+    ecs_entity_t local_id, world_id, system;
+    yh_ctx* ctx;
+    yh_scene* scene;
+    uint64_t scene_entities;
+    uint32_t scene_levels;
+
+    Batch* batches;
+    uint32_t n_batches, cap_batches;
+    ecs_entity_t* walk_entities;   /* this walk, walk order */
+    ecs_entity_t* cached_entities; /* last walk */
+    ecs_entity_t* cached_src;      /* last walk, per batch */
+    uint32_t* cached_counts;
+    int32_t* cached_levels;
+    uint32_t cached_batches;
+    uint64_t n, cap_n, cached_n;
+
+    ecs_entity_t* entity_of_slot;
+    uint32_t* order; /* batch indices in slot order */
+    uint8_t* stage_w;
+    uint8_t* stage_l;
+    uint32_t n_levels;
+
+    BoundsEntry* bounds;
+    uint64_t bounds_cap, bounds_n;
+    int bounds_stale;
+
+    float planes[YH_MAX_FRUSTA * 24];
+    uint32_t n_frusta;
+
+    int status;
+    uint64_t rebuilds;
+};
+
+/* ---- small open-addressing maps (entity ids are never 0) ------------------------------------------------- */
+static uint64_t hash64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+static int map_init(Map* m, uint64_t n) {
+    uint64_t cap = 16;
+    while (cap < n * 2) cap <<= 1;
+    m->e = (MapEntry*)calloc(cap, sizeof(MapEntry));
+    m->cap = cap;
+    return m->e ? 0 : -1;
+}
+
+static void map_put(Map* m, ecs_entity_t k, uint32_t v) {
+    uint64_t i = hash64(k) & (m->cap - 1);
+    while (m->e[i].key && m->e[i].key != k) i = (i + 1) & (m->cap - 1);
+    m->e[i].key = k;
+    m->e[i].value = v;
+}
+
+static int map_get(const Map* m, ecs_entity_t k, uint32_t* v) {
+    uint64_t i = hash64(k) & (m->cap - 1);
+    while (m->e[i].key) {
+        if (m->e[i].key == k) {
+            *v = m->e[i].value;
+            return 1;
+        }
+        i = (i + 1) & (m->cap - 1);
+    }
+    return 0;
+}
+
+static BoundsEntry* bounds_find(const GpuTransformCullSystem* s, ecs_entity_t k) {
+    if (!s->bounds_cap) return NULL;
+    uint64_t i = hash64(k) & (s->bounds_cap - 1);
+    while (s->bounds[i].key) {
+        if (s->bounds[i].key == k) return &s->bounds[i];
+        i = (i + 1) & (s->bounds_cap - 1);
+    }
+    return NULL;
+}
+
+static int bounds_grow(GpuTransformCullSystem* s) {
+    const uint64_t old_cap = s->bounds_cap;
+    BoundsEntry* old = s->bounds;
+    const uint64_t cap = old_cap ? old_cap * 2 : 1024;
+    BoundsEntry* fresh = (BoundsEntry*)calloc(cap, sizeof(BoundsEntry));
+    if (!fresh) return YH_ERR_OOM;
+    s->bounds = fresh;
+    s->bounds_cap = cap;
+    for (uint64_t j = 0; j < old_cap; ++j) {
+        if (!old[j].key) continue;
+        uint64_t i = hash64(old[j].key) & (cap - 1);
+        while (fresh[i].key) i = (i + 1) & (cap - 1);
+        fresh[i] = old[j];
+    }
+    free(old);
+    return YH_OK;
+}
+
+/* ---- the walk ---------------------------------------------------------------------------------------------- */
+static int reserve_rows(GpuTransformCullSystem* s, uint64_t need) {
+    if (need <= s->cap_n) return YH_OK;
+    uint64_t cap = s->cap_n ? s->cap_n : 1024;
+    while (cap < need) cap *= 2;
+    ecs_entity_t* a = (ecs_entity_t*)realloc(s->walk_entities, cap * sizeof(ecs_entity_t));
+    if (!a) return YH_ERR_OOM;
+    s->walk_entities = a;
+    s->cap_n = cap;
+    return YH_OK;
+}
+
+static int walk(GpuTransformCullSystem* s, ecs_iter_t* it) {
+    int rc = YH_OK;
+    s->n_batches = 0;
+    s->n = 0;
+    while (ecs_iter_next(it)) { /* must run to the end even after an error: the iterator owns resources */
+        if (rc != YH_OK || it->count == 0) continue;
+        if (s->n_batches == s->cap_batches) {
+            const uint32_t cap = s->cap_batches ? s->cap_batches * 2 : 256;
+            Batch* b = (Batch*)realloc(s->batches, cap * sizeof(Batch));
+            if (!b) {
+                rc = YH_ERR_OOM;
+                continue;
+            }
+            s->batches = b;
+            s->cap_batches = cap;
+        }
+        if (s->n + (uint64_t)it->count > 0x40000000ull) {
+            rc = YH_ERR_UNSUPPORTED;
+            continue;
+        }
+        if ((rc = reserve_rows(s, s->n + (uint64_t)it->count)) != YH_OK) continue;
+        Batch* b = &s->batches[s->n_batches++];
+        b->world_col = ecs_field_w_size(it, ROW, 0);
+        b->local_col = ecs_field_w_size(it, ROW, 1);
+        b->up_row = ecs_field_w_size(it, ROW, 2);
+        b->src = ecs_field_src(it, 2);
+        b->count = (uint32_t)it->count;
+        b->walk_begin = (uint32_t)s->n;
+        b->slot_begin = 0;
+        b->level = -1;
+        memcpy(s->walk_entities + s->n, it->entities, sizeof(ecs_entity_t) * (size_t)it->count);
+        s->n += (uint64_t)it->count;
+    }
+    return rc;
+}
+
+static int same_as_last_walk(const GpuTransformCullSystem* s) {
+    if (!s->scene || s->n != s->cached_n || s->n_batches != s->cached_batches) return 0;
+    for (uint32_t i = 0; i < s->n_batches; ++i)
+        if (s->batches[i].src != s->cached_src[i] || s->batches[i].count != s->cached_counts[i]) return 0;
+    return memcmp(s->walk_entities, s->cached_entities, s->n * sizeof(ecs_entity_t)) == 0;
+}
+
+/* ---- rebuild of the slot order ----------------------------------------------------------------------------- */
+static const uint32_t* g_sort_key;
+static int by_key(const void* a, const void* b) {
+    const uint32_t ia = *(const uint32_t*)a, ib = *(const uint32_t*)b;
+    if (g_sort_key[ia] != g_sort_key[ib]) return g_sort_key[ia] < g_sort_key[ib] ? -1 : 1;
+    return ia < ib ? -1 : (ia > ib); /* stable: walk order among equals */
+}
+
+static int rebuild(GpuTransformCullSystem* s) {
+    const uint64_t n = s->n;
+    const uint32_t nb = s->n_batches;
+    int rc = YH_OK;
+    Map batch_of = {0};
+    uint32_t* parent_batch = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
+    uint32_t* parent_row = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1)); /* walk row of the parent */
+    uint32_t* key = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
+    uint32_t* parent_index = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
+    uint32_t* stack = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
+    uint32_t level_offsets[YH_MAX_LEVELS + 1];
+    free(s->order);
+    s->order = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
+    if (!parent_batch || !parent_row || !key || !parent_index || !stack || !s->order || map_init(&batch_of, n) != 0) {
+        rc = YH_ERR_OOM;
+        goto done;
+    }
+    /* entity -> walk row; the batch of a row is found by binary search over walk_begin */
+    for (uint64_t r = 0; r < n; ++r) map_put(&batch_of, s->walk_entities[r], (uint32_t)r);
+    for (uint32_t b = 0; b < nb; ++b) {
+        uint32_t row;
+        if (map_get(&batch_of, s->batches[b].src, &row)) {
+            uint32_t lo = 0, hi = nb - 1;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) / 2;
+                if (s->batches[mid].walk_begin <= row) lo = mid;
+                else hi = mid - 1;
+            }
+            parent_batch[b] = lo;
+            parent_row[b] = row;
+        } else {
+            parent_batch[b] = YH_NO_PARENT; /* the scene root, or any holder of a WorldTransform without a local one */
+            parent_row[b] = YH_NO_PARENT;
+        }
+    }
+    /* levels, memoised along parent chains (ChildOf is acyclic) */
+    uint32_t n_levels = 0;
+    for (uint32_t b = 0; b < nb; ++b) {
+        uint32_t top = 0, cur = b;
+        while (s->batches[cur].level < 0 && parent_batch[cur] != YH_NO_PARENT) {
+            stack[top++] = cur;
+            cur = parent_batch[cur];
+            if (top >= nb) break;
+        }
+        if (s->batches[cur].level < 0) s->batches[cur].level = 0;
+        int32_t lvl = s->batches[cur].level;
+        while (top) s->batches[stack[--top]].level = ++lvl;
+        if ((uint32_t)s->batches[b].level + 1 > n_levels) n_levels = (uint32_t)s->batches[b].level + 1;
+    }
+    if (n_levels > YH_MAX_LEVELS) {
+        rc = YH_ERR_UNSUPPORTED;
+        goto done;
+    }
+    /* level by level: order the level's batches by the slot of their parent, hand out slots */
+    uint32_t placed = 0, slot = 0;
+    for (uint32_t lvl = 0; lvl < n_levels; ++lvl) {
+        level_offsets[lvl] = slot;
+        const uint32_t first = placed;
+        for (uint32_t b = 0; b < nb; ++b) {
+            if ((uint32_t)s->batches[b].level != lvl) continue;
+            if (lvl == 0) {
+                key[b] = 0;
+            } else {
+                const Batch* pb = &s->batches[parent_batch[b]];
+                key[b] = pb->slot_begin + (parent_row[b] - pb->walk_begin); /* parent's slot: assigned one level up */
+            }
+            s->order[placed++] = b;
+        }
+        g_sort_key = key;
+        qsort(s->order + first, placed - first, sizeof(uint32_t), by_key);
+        for (uint32_t i = first; i < placed; ++i) {
+            Batch* b = &s->batches[s->order[i]];
+            b->slot_begin = slot;
+            const uint32_t p = lvl == 0 ? YH_NO_PARENT : key[s->order[i]];
+            for (uint32_t r = 0; r < b->count; ++r) parent_index[slot + r] = p;
+            slot += b->count;
+        }
+    }
+    level_offsets[n_levels] = slot;
+
+    if (!s->scene || s->scene_entities != n || s->scene_levels != n_levels) {
+        if (s->scene) yh_scene_destroy(s->scene);
+        s->scene = NULL;
+        yh_scene_desc d;
+        memset(&d, 0, sizeof d);
+        d.n_entities = n;
+        d.n_levels = n_levels;
+        d.n_frusta = YH_MAX_FRUSTA;
+        d.local_kind = YH_LOCAL_MAT4;
+        d.bounds_kind = YH_BOUNDS_PER_ENTITY;
+        if ((rc = yh_scene_create(s->ctx, &d, &s->scene)) != YH_OK) goto done;
+        s->scene_entities = n;
+        s->scene_levels = n_levels;
+        uint8_t* w = (uint8_t*)realloc(s->stage_w, (size_t)n * ROW);
+        if (w) s->stage_w = w;
+        uint8_t* l = (uint8_t*)realloc(s->stage_l, (size_t)n * ROW);
+        if (l) s->stage_l = l;
+        ecs_entity_t* eo = (ecs_entity_t*)realloc(s->entity_of_slot, (size_t)n * sizeof(ecs_entity_t));
+        if (eo) s->entity_of_slot = eo;
+        if (!w || !l || !eo) {
+            rc = YH_ERR_OOM;
+            goto done;
+        }
+    }
+    if ((rc = yh_upload_hierarchy(s->scene, parent_index, level_offsets)) != YH_OK) goto done;
+    for (uint32_t b = 0; b < nb; ++b)
+        memcpy(s->entity_of_slot + s->batches[b].slot_begin, s->walk_entities + s->batches[b].walk_begin,
+               sizeof(ecs_entity_t) * s->batches[b].count);
+    s->n_levels = n_levels;
+    s->bounds_stale = 1;
+
+    /* remember this walk */
+    {
+        ecs_entity_t* ce = (ecs_entity_t*)realloc(s->cached_entities, (size_t)(n ? n : 1) * sizeof(ecs_entity_t));
+        ecs_entity_t* cs = (ecs_entity_t*)realloc(s->cached_src, (size_t)(nb ? nb : 1) * sizeof(ecs_entity_t));
+        uint32_t* cc = (uint32_t*)realloc(s->cached_counts, (size_t)(nb ? nb : 1) * sizeof(uint32_t));
+        int32_t* cl = (int32_t*)realloc(s->cached_levels, (size_t)(nb ? nb : 1) * sizeof(int32_t));
+        if (cl) s->cached_levels = cl;
+        if (ce) s->cached_entities = ce;
+        if (cs) s->cached_src = cs;
+        if (cc) s->cached_counts = cc;
+        if (!ce || !cs || !cc || !cl) {
+            s->cached_n = 0;
+            s->cached_batches = 0;
+            rc = YH_ERR_OOM;
+            goto done;
+        }
+        memcpy(ce, s->walk_entities, (size_t)n * sizeof(ecs_entity_t));
+        for (uint32_t b = 0; b < nb; ++b) {
+            cs[b] = s->batches[b].src;
+            cc[b] = s->batches[b].count;
+            cl[b] = s->batches[b].level;
+        }
+        s->cached_n = n;
+        s->cached_batches = nb;
+    }
+    s->rebuilds += 1;
+done:
+    free(batch_of.e);
+    free(parent_batch);
+    free(parent_row);
+    free(key);
+    free(parent_index);
+    free(stack);
+    if (rc != YH_OK) s->cached_n = 0, s->cached_batches = 0;
+    return rc;
+}
+
+static int upload_bounds(GpuTransformCullSystem* s) {
+    const uint64_t n = s->n;
+    float* planes = (float*)calloc((size_t)n * 6, sizeof(float)); /* no bounds = empty box at the origin */
+    if (!planes) return YH_ERR_OOM;
+    if (s->bounds_n)
+        for (uint64_t e = 0; e < n; ++e) {
+            const BoundsEntry* b = bounds_find(s, s->entity_of_slot[e]);
+            if (b)
+                for (int k = 0; k < 6; ++k) planes[(size_t)k * n + e] = b->mm[k];
+        }
+    const float* mn[3] = {planes, planes + n, planes + 2 * n};
+    const float* mx[3] = {planes + 3 * n, planes + 4 * n, planes + 5 * n};
+    const int rc = yh_upload_aabb(s->scene, mn, mx, 0, n);
+    free(planes);
+    if (rc == YH_OK) s->bounds_stale = 0;
+    return rc;
+}
+
+/* when slots are restored from the cached order only slot_begin / level need refreshing: same walk, same order */
+static void restore_slots(GpuTransformCullSystem* s) {
+    uint32_t slot = 0;
+    for (uint32_t i = 0; i < s->n_batches; ++i) {
+        Batch* b = &s->batches[s->order[i]];
+        b->level = s->cached_levels[s->order[i]];
+        b->slot_begin = slot;
+        slot += b->count;
+    }
+}
+
+static void run(ecs_iter_t* it) {
+    GpuTransformCullSystem* s = (GpuTransformCullSystem*)it->ctx;
+    int rc = walk(s, it);
+    if (rc != YH_OK || s->n == 0) {
+        s->status = rc;
+        return;
+    }
+    if (same_as_last_walk(s)) restore_slots(s);
+    else if ((rc = rebuild(s)) != YH_OK) {
+        s->status = rc;
+        return;
+    }
+    if (s->bounds_stale && (rc = upload_bounds(s)) != YH_OK) {
+        s->status = rc;
+        return;
+    }
+    /* the scene root: every level-0 table must name the same holder of the parent matrix */
+    uint8_t* root_row = NULL;
+    ecs_entity_t root = 0;
+    for (uint32_t i = 0; i < s->n_batches; ++i) {
+        const Batch* b = &s->batches[i];
+        if (b->level != 0) continue;
+        if (!root) {
+            root = b->src;
+            root_row = (uint8_t*)b->up_row;
+        } else if (root != b->src) {
+            s->status = YH_ERR_UNSUPPORTED; /* more than one root transform: not a reference scene (GameApp.zig:77) */
+            return;
+        }
+    }
+    /* matrix and dirty byte exactly as level-0 rows read them through the Up term */
+    if (root_row && (rc = yh_upload_root_aos68(s->scene, root_row)) != YH_OK) {
+        s->status = rc;
+        return;
+    }
+    for (uint32_t i = 0; i < s->n_batches; ++i) {
+        const Batch* b = &s->batches[i];
+        memcpy(s->stage_w + (size_t)b->slot_begin * ROW, b->world_col, (size_t)b->count * ROW);
+        memcpy(s->stage_l + (size_t)b->slot_begin * ROW, b->local_col, (size_t)b->count * ROW);
+    }
+    if ((rc = yh_upload_world_aos68(s->scene, s->stage_w, 0, s->n)) != YH_OK ||
+        (rc = yh_upload_local_aos68(s->scene, s->stage_l, 0, s->n)) != YH_OK ||
+        (rc = yh_frame(s->scene, s->planes, s->n_frusta, s->n_frusta ? 0u : YH_FRAME_NO_CULL)) != YH_OK ||
+        (rc = yh_download_world_aos68(s->scene, s->stage_w, 0, s->n)) != YH_OK ||
+        (rc = yh_download_local_aos68(s->scene, s->stage_l, 0, s->n)) != YH_OK) {
+        s->status = rc;
+        return;
+    }
+    for (uint32_t i = 0; i < s->n_batches; ++i) {
+        const Batch* b = &s->batches[i];
+        memcpy(b->world_col, s->stage_w + (size_t)b->slot_begin * ROW, (size_t)b->count * ROW);
+        memcpy(b->local_col, s->stage_l + (size_t)b->slot_begin * ROW, (size_t)b->count * ROW);
+    }
+    if (root_row) root_row[64] = 0; /* PostWorldTransform reaches the root too (single-term query) */
+    s->status = YH_OK;
+}
+
+/* ---- public ------------------------------------------------------------------------------------------------ */
+ecs_entity_t GpuTransformCullSystem_registerTo(ecs_world_t* world, ecs_entity_t local_transform,
+                                               ecs_entity_t world_transform, yh_ctx* ctx,
+                                               GpuTransformCullSystem** out_state) {
+    if (!world || !ctx || !out_state || !local_transform || !world_transform) return 0;
+    GpuTransformCullSystem* s = (GpuTransformCullSystem*)calloc(1, sizeof *s);
+    if (!s) return 0;
+    s->world = world;
+    s->local_id = local_transform;
+    s->world_id = world_transform;
+    s->ctx = ctx;
+
+    ecs_entity_desc_t ed;
+    memset(&ed, 0, sizeof ed);
+    ed.name = "GpuTransformCullSystem";
+    ecs_id_t add[3] = {ecs_pair(EcsDependsOn, EcsPostUpdate), EcsPostUpdate, 0}; /* ecs.zig:1224-1235 */
+    ed.add = add;
+    ecs_system_desc_t sd;
+    memset(&sd, 0, sizeof sd);
+    sd.entity = ecs_entity_init(world, &ed);
+    sd.run = run;
+    sd.ctx = s;
+    sd.query.terms[0].id = world_transform;
+    sd.query.terms[0].inout = EcsInOut;
+    sd.query.terms[1].id = local_transform;
+    sd.query.terms[1].inout = EcsInOut;
+    sd.query.terms[2].id = world_transform;
+    sd.query.terms[2].inout = EcsIn;
+    sd.query.terms[2].src.id = EcsUp;
+    s->system = ecs_system_init(world, &sd);
+    if (!s->system) {
+        free(s);
+        return 0;
+    }
+    *out_state = s;
+    return s->system;
+}
+
+int GpuTransformCullSystem_setBounds(GpuTransformCullSystem* s, ecs_entity_t entity, const float min_max[6]) {
+    if (!s || !entity || !min_max) return YH_ERR_BAD_ARG;
+    BoundsEntry* b = bounds_find(s, entity);
+    if (!b) {
+        if ((s->bounds_n + 1) * 2 > s->bounds_cap) {
+            const int rc = bounds_grow(s);
+            if (rc != YH_OK) return rc;
+        }
+        uint64_t i = hash64(entity) & (s->bounds_cap - 1);
+        while (s->bounds[i].key) i = (i + 1) & (s->bounds_cap - 1);
+        b = &s->bounds[i];
+        b->key = entity;
+        s->bounds_n += 1;
+    }
+    memcpy(b->mm, min_max, sizeof b->mm);
+    s->bounds_stale = 1;
+    return YH_OK;
+}
+
+int GpuTransformCullSystem_setFrusta(GpuTransformCullSystem* s, const float* planes, uint32_t n_frusta) {
+    if (!s || n_frusta > YH_MAX_FRUSTA || (n_frusta && !planes)) return YH_ERR_BAD_ARG;
+    if (n_frusta) memcpy(s->planes, planes, sizeof(float) * 24u * n_frusta);
+    s->n_frusta = n_frusta;
+    return YH_OK;
+}
+
+uint64_t GpuTransformCullSystem_visible(GpuTransformCullSystem* s, uint32_t frustum, ecs_entity_t* out, uint64_t cap) {
+    if (!s || !s->scene || frustum >= s->n_frusta) return 0;
+    uint32_t counts[YH_MAX_FRUSTA], bnd[YH_MAX_FRUSTA];
+    if (yh_get_counts(s->scene, counts, bnd) != YH_OK) return 0;
+    const uint64_t total = counts[frustum];
+    if (!out || !cap || !total) return total;
+    uint32_t* slots = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)total);
+    if (!slots) return 0;
+    uint64_t written = 0;
+    if (yh_get_draw_list(s->scene, frustum, slots, total, &written) != YH_OK) {
+        free(slots);
+        return 0;
+    }
+    const uint64_t m = written < cap ? written : cap;
+    for (uint64_t i = 0; i < m; ++i) out[i] = s->entity_of_slot[slots[i]];
+    free(slots);
+    return written;
+}
+
+int GpuTransformCullSystem_status(const GpuTransformCullSystem* s) { return s ? s->status : YH_ERR_BAD_ARG; }
+uint64_t GpuTransformCullSystem_entities(const GpuTransformCullSystem* s) { return s ? s->n : 0; }
+uint32_t GpuTransformCullSystem_levels(const GpuTransformCullSystem* s) { return s ? s->n_levels : 0; }
+uint64_t GpuTransformCullSystem_rebuilds(const GpuTransformCullSystem* s) { return s ? s->rebuilds : 0; }
+
+void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
+    if (!s) return;
+    if (s->scene) yh_scene_destroy(s->scene);
+    free(s->batches);
+    free(s->walk_entities);
+    free(s->cached_entities);
+    free(s->cached_src);
+    free(s->cached_counts);
+    free(s->cached_levels);
+    free(s->entity_of_slot);
+    free(s->order);
+    free(s->stage_w);
+    free(s->stage_l);
+    free(s->bounds);
+    free(s);
+}
