@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyume_hip.so")
+# YUME_HIP_LIB: development knob for A/B runs of two builds of the same library; never a different implementation
+LIB_PATH = os.environ.get("YUME_HIP_LIB") or os.path.join(_HERE, "libyume_hip.so")
 
 YH_MAX_FRUSTA = 8
 YH_MAX_LEVELS = 64
