@@ -171,10 +171,14 @@ int yh_timings(yh_scene* s, yh_timing* out);
 int yh_scene_set_kernel_timing(yh_scene* s, int enable);
 int yh_scene_get_groups(yh_scene* s, uint32_t* quads, uint32_t cap, uint32_t* n_groups);
 int yh_scene_get_group_timings(yh_scene* s, float* mean_ms, uint32_t* samples, uint32_t cap);
-/* Hierarchy launches: levels are cut into groups of consecutive levels, one kernel launch per group;
- * inside a group an entity re-derives its ancestors' matrices instead of waiting for them.
- * max_group_levels = 1 is one launch per level; 0 = automatic.                                           */
+/* Hierarchy launches (TRS scenes): levels are cut into groups of consecutive levels, one kernel launch per
+ * group; inside a group an entity re-derives its ancestors' matrices (a walk up the parent chain) instead of
+ * waiting for a launch boundary.  Results do not depend on the plan.  yh_scene_set_grouping: exactly
+ * max_group_levels (<= 8) levels per launch, 1 = one launch per level, 0 = the planner decides.
+ * yh_scene_set_plan: explicit plan, group i = levels (last_level[i-1], last_level[i]], at most 8 each;
+ * n_groups = 0 returns to the planner.                                                                   */
 int yh_scene_set_grouping(yh_scene* s, uint32_t max_group_levels);
+int yh_scene_set_plan(yh_scene* s, uint32_t n_groups, const uint32_t* last_level);
 
 /* ---- frustum helpers (host, scalar; same arithmetic as the kernels' inputs expect) --------------------- */
 /* Gribb-Hartmann planes from a column-major view-projection matrix (camera.zig:300-302; depth 0..1 as

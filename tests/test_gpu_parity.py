@@ -175,6 +175,34 @@ def test_cfg2_tree_1m(ctx, oracle, group):
         check_frame(oracle, s, lo, par, trs, bounds, oracle.main_camera_planes())
 
 
+@pytest.mark.parametrize("plan", [[7], [3, 7], [5, 7], [0, 1, 2, 3, 4, 5, 6, 7], [1, 4, 7], [0, 6, 7]])
+def test_explicit_launch_plans_give_identical_results(ctx, oracle, plan):
+    from yume_amd import _lib
+
+    lo, par, trs, bounds = make_scene(oracle, 50_000, 8)
+    with gpu_scene(ctx, lo, par, trs, bounds, 1) as s:
+        s.set_plan(plan)
+        g = s.groups()
+        assert [int(q[1]) for q in g] == plan and int(g[0][0]) == 0
+        check_frame(oracle, s, lo, par, trs, bounds, oracle.main_camera_planes())
+        s.set_plan()  # back to the planner
+        check_frame(oracle, s, lo, par, trs, bounds, oracle.main_camera_planes())
+        for bad in ([3, 6], [3, 3, 7], [8], [7, 7]):  # not covering, not increasing, out of range
+            with pytest.raises(_lib.YumeHipError) as e:
+                s.set_plan(bad)
+            assert e.value.code == _lib.YH_ERR_BAD_ARG
+
+
+def test_planner_groups_small_levels_and_triples_large_ones(ctx, oracle):
+    from yume_amd import Scene
+
+    for n, expect in ((1_000_000, [5, 7]), (12_500_000, [1, 4, 7]), (4096, [7])):
+        lo = oracle.synth_level_offsets(n, 8)
+        with Scene(ctx, n, n_levels=8, n_frusta=0, bounds_kind=0) as s:
+            s.upload_hierarchy(oracle.synth_parents(lo), lo)
+            assert [int(q[1]) for q in s.groups()] == expect
+
+
 def test_deep_and_uneven_hierarchy(ctx, oracle):
     """12 levels with hand-made uneven level sizes (some levels smaller than their parent level), root != identity."""
     sizes = [3, 50, 7, 900, 901, 20, 4000, 1, 300, 2000, 5, 1024]

@@ -172,6 +172,11 @@ class Scene:
     def set_grouping(self, max_group_levels):
         self._ck(L.lib().yh_scene_set_grouping(self._h, int(max_group_levels)))
 
+    def set_plan(self, last_levels=()):
+        """Explicit launch plan: group i ends at level last_levels[i]; empty = back to the planner."""
+        ll = np.ascontiguousarray(last_levels, np.uint32)
+        self._ck(L.lib().yh_scene_set_plan(self._h, ll.size, _ptr(ll) if ll.size else None))
+
     # ---- per frame ----
     def frame(self, planes=None, flags=L.YH_FRAME_ALL_DIRTY):
         if planes is None:

@@ -24,7 +24,7 @@
 #define YH_K_MAX_FRUSTA 8
 #define YH_BLOCK 256
 #define YH_MAX_ITERS 8 /* a workgroup handles iters x 256 consecutive entities */
-#define YH_MAX_GROUP 8 /* levels one launch may span */
+#define YH_MAX_GROUP 8 /* levels one launch may span (k_frame_chain) */
 #define YH_CHUNK 64
 
 struct FrameArgs {
@@ -40,7 +40,7 @@ struct FrameArgs {
     uint64_t* vismask;   // [frustum][n_chunks] one visibility bit per entity (wave ballots)
     uint32_t n_chunks;
     uint32_t begin, end;               // entity range of this launch (levels lo..hi)
-    uint32_t lvl_begin[YH_MAX_GROUP];  // first slot of levels lo+1, lo+2, ... (0xFFFFFFFF when absent)
+    uint32_t lvl_begin[YH_MAX_GROUP];  // chain kernel: first slot of levels lo+1, lo+2, ... (0xFFFFFFFF when absent)
     uint32_t n_frusta;
     uint32_t id_base;
     uint32_t n_meshes;
@@ -136,31 +136,24 @@ __device__ __forceinline__ void load_inputs(const FrameArgs& a, uint32_t e, TrsI
 
 // ---------------------------------------------------------------------------------------------------
 // Fused frame kernel, TRS locals, every LocalTransform dirty (forward branch of
-// TransformSyncSystem.zig:67-68 on every row).
-//
-// One launch covers a GROUP of up to G consecutive levels.  An entity at depth d inside the group walks
-// its d ancestors inside the group, starts from the stored world matrix of the group's base parent (or
-// the scene root) and multiplies down: W = ((base * L_a0) * L_a1) ... * L_self — the same products in the
-// same order as level-by-level propagation, so the values are identical; the recomputation trades a few
-// hundred VALU ops (free under the HBM bound) for G-1 fewer dependent launches.
-//   stage 1: Mat4.compose per chain element   stage 2: Mat4.mul chain   stage 3: cull + compaction.
+// TransformSyncSystem.zig:67-68 on every row), ONE level per launch:
+//   stage 1: Mat4.compose   stage 2: W = W_parent * L   stage 3: cull + visibility ballot.
 // A workgroup walks `iters` slices of 256 consecutive entities; with PREFETCH the streamed inputs of slice
-// i+1 are requested before slice i is computed (register double buffer), so the parent gather of a slice
-// never waits for its own index load.  BOUNDS: 0 none, 1 per-entity planes, 2 mesh table.  HAS_BASE: the
-// group's first level is > 0 (its entities have stored parents).
-template <int G, int BOUNDS, bool HAS_BASE, bool PREFETCH>
+// i+1 are requested before slice i is computed (register double buffer).  BOUNDS: 0 none, 1 per-entity
+// planes, 2 mesh table.  HAS_BASE: the level is > 0 (its entities have stored parents), else the parent
+// is the scene root.
+template <int BOUNDS, bool HAS_BASE, bool PREFETCH>
 __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs(const FrameArgs a) {
     const uint32_t tid = threadIdx.x;
     const uint32_t tile = a.iters * YH_BLOCK;
     // chunk-aligned mapping: every wave covers exactly one 64-entity chunk of the arrays
     const uint64_t tile0 = (uint64_t)(a.begin & ~63u) + (uint64_t)blockIdx.x * tile;
     const uint32_t last = a.end - 1;
-    constexpr bool NEED_PARENT = HAS_BASE || (G > 1);
     // lanes outside [begin, end) redo a valid entity of the launch and store nothing
     auto clamp_e = [&](uint64_t e64) -> uint32_t { return e64 < a.begin ? a.begin : (e64 < a.end ? (uint32_t)e64 : last); };
 
     TrsInputs<BOUNDS> cur;
-    if (PREFETCH) load_inputs<BOUNDS, NEED_PARENT>(a, clamp_e(tile0 + tid), cur);
+    if (PREFETCH) load_inputs<BOUNDS, HAS_BASE>(a, clamp_e(tile0 + tid), cur);
 #pragma unroll 1
     for (uint32_t it = 0; it < a.iters; ++it) {
         const uint64_t e64 = tile0 + (uint64_t)it * YH_BLOCK + tid;
@@ -170,40 +163,16 @@ __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs(const FrameArgs a) {
         TrsInputs<BOUNDS> nxt;
         if (PREFETCH) {
             nxt = cur;
-            if (it + 1 < a.iters) load_inputs<BOUNDS, NEED_PARENT>(a, clamp_e(e64 + YH_BLOCK), nxt);
+            if (it + 1 < a.iters) load_inputs<BOUNDS, HAS_BASE>(a, clamp_e(e64 + YH_BLOCK), nxt);
         } else {
-            load_inputs<BOUNDS, NEED_PARENT>(a, e, cur);
-        }
-        // depth of e inside the group, and its ancestor chain: chain[0] = e, chain[j] = parent of chain[j-1]
-        int d = 0;
-#pragma unroll
-        for (int j = 0; j < G - 1; ++j) d += (e >= a.lvl_begin[j]) ? 1 : 0;
-        uint32_t chain[G];
-        uint32_t p = e;
-        uint32_t pp = cur.pidx;  // parent slot of p (meaningful while p has a stored parent)
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-            chain[j] = p;
-            if (j < d) {
-                p = pp;
-                if (HAS_BASE || j + 1 < d) pp = a.parent[p];
-            }
+            load_inputs<BOUNDS, HAS_BASE>(a, e, cur);
         }
         M4 w;
         if (HAS_BASE) {
-            load_row<16>(a.world, pp, w.v);
+            load_row<16>(a.world, cur.pidx, w.v);
         } else {
 #pragma unroll
             for (int q = 0; q < 16; ++q) w.v[q] = a.root[q];
-        }
-#pragma unroll
-        for (int j = G - 1; j >= 1; --j) {
-            if (j <= d) {
-                float t[10];
-                load_row<10>(a.trs, chain[j], t);
-                const M4 l = m4_compose(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
-                w = m4_mul(w, l);
-            }
         }
         {
             const M4 l = m4_compose(cur.t[0], cur.t[1], cur.t[2], cur.t[3], cur.t[4], cur.t[5], cur.t[6], cur.t[7],
@@ -219,6 +188,63 @@ __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs(const FrameArgs a) {
             publish_visible(a, (uint32_t)(e64 >> 6), c0 < a.begin, vmask, bmask);
         }
         if (PREFETCH) cur = nxt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Chain kernel: one launch for a GROUP of up to G consecutive levels.  An entity at depth d inside the group
+// walks its d ancestors inside the group, starts from the stored world matrix of the group's base parent (or
+// the scene root) and multiplies down: W = ((base * L_a0) * L_a1) ... * L_self — the same products in the
+// same order as level-by-level propagation, so the values are identical; the recomputation trades VALU work
+// and a dependent walk up the parent chain for G-1 fewer dependent launches.  Best for shallow groups of
+// small levels (the top of a tree), where a launch boundary costs more than the level's own traffic.
+template <int G, int BOUNDS, bool HAS_BASE>
+__global__ __launch_bounds__(YH_BLOCK) void k_frame_chain(const FrameArgs a) {
+    const uint32_t tid = threadIdx.x;
+    const uint64_t e64 = (uint64_t)(a.begin & ~63u) + (uint64_t)blockIdx.x * YH_BLOCK + tid;
+    if (e64 - (tid & 63u) >= a.end) return;  // this wave's chunk starts past the end (wave-uniform)
+    const bool valid = e64 >= a.begin && e64 < a.end;
+    const uint32_t e = e64 < a.begin ? a.begin : (e64 < a.end ? (uint32_t)e64 : a.end - 1u);
+    TrsInputs<BOUNDS> cur;
+    load_inputs<BOUNDS, true>(a, e, cur);
+    // depth of e inside the group, and its ancestor chain: chain[0] = e, chain[j] = parent of chain[j-1]
+    int d = 0;
+#pragma unroll
+    for (int j = 0; j < G - 1; ++j) d += (e >= a.lvl_begin[j]) ? 1 : 0;
+    uint32_t chain[G];
+    uint32_t p = e;
+    uint32_t pp = cur.pidx;  // parent slot of p (meaningful while p has a stored parent)
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        chain[j] = p;
+        if (j < d) {
+            p = pp;
+            if (HAS_BASE || j + 1 < d) pp = a.parent[p];
+        }
+    }
+    M4 w;
+    if (HAS_BASE) {
+        load_row<16>(a.world, pp, w.v);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w.v[q] = a.root[q];
+    }
+#pragma unroll
+    for (int j = G - 1; j >= 1; --j) {
+        if (j <= d) {
+            float t[10];
+            load_row<10>(a.trs, chain[j], t);
+            w = m4_mul(w, m4_compose(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]));
+        }
+    }
+    w = m4_mul(w, m4_compose(cur.t[0], cur.t[1], cur.t[2], cur.t[3], cur.t[4], cur.t[5], cur.t[6], cur.t[7], cur.t[8],
+                             cur.t[9]));
+    if (valid) store_row<16>(a.world, e, w.v);
+    if (BOUNDS != 0) {
+        uint32_t vmask = 0, bmask = 0;
+        cull_entity<BOUNDS>(a, w, cur.b, cur.mesh, vmask, bmask);
+        if (!valid) vmask = bmask = 0;
+        publish_visible(a, (uint32_t)(e64 >> 6), e64 - (tid & 63u) < a.begin, vmask, bmask);
     }
 }
 
@@ -291,69 +317,51 @@ __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, cons
     }
 }
 
-// ---- stage 3 back end, part 2: prefix sums + expansion into ordered draw lists -----------------------------
-// An expand tile is `words` visibility words (64 = 4096 entities, or 256 for scenes beyond 16M entities).
-// k_count reduces every tile to its visible count; k_expand gives one workgroup to each (tile, frustum): its base
-// is the sum of the tile counts before it (read redundantly: a few thousand L2-resident words, cheaper than a
-// dependent scan launch), the tile's words are prefix-summed through LDS and the 4 waves expand them
-// round-robin, one word per step: lane l emits entity chunk*64+l at rank mbcnt(word).  Ascending entity order,
-// coalesced stores, no atomics.  Scenes of at most YH_SELF_COUNT_TILES tiles skip k_count: every workgroup
-// popcounts the words before its tile itself.
+// ---- stage 3 back end, part 2: single-pass prefix sums + expansion into ordered draw lists ------------------
+// An expand tile is `words` visibility words (64 = 4096 entities, or 256 for scenes beyond 16M entities); one
+// workgroup per (tile, frustum).  The tile's words are prefix-summed through LDS; the tile's base (visible
+// entities in the tiles before it) comes from a decoupled look-back over 64-bit status words
+//     [63:34] frame epoch   [33:32] 1 = tile aggregate, 2 = inclusive prefix   [31:0] value
+// which every workgroup publishes as soon as it knows them (one relaxed agent-scope store; epoch-tagged, so
+// nothing is cleared between frames).  Wave 0 reads the 64 statuses before its tile at a time and stops at the
+// nearest inclusive prefix.  A status that has not appeared after YH_LOOKBACK_POLLS reads is not waited for: the
+// reader popcounts that tile's visibility words itself (they are final before this launch starts), so the kernel
+// terminates whatever order the workgroups are scheduled in.  Then the 4 waves expand the words round-robin, one
+// word per step: lane l emits entity chunk*64+l at rank mbcnt(word).  Ascending entity order, coalesced stores,
+// no atomics on shared addresses, no separate counting launch.
 #define YH_EXPAND_WORDS_MAX 256
-#define YH_SELF_COUNT_TILES 8
+#define YH_LOOKBACK_POLLS 2048
 
 struct ExpandArgs {
     const uint64_t* vismask;
-    uint32_t* tilecnt;      // [frustum][n_tiles]
+    uint64_t* status;       // [frustum][n_tiles] look-back words
     uint32_t* counts;       // device totals [frustum] (input of the RCCL all-gather)
     uint32_t* bcount_cur;   // boundary counters accumulated by this frame's launches
     uint32_t* bcount_next;  // the other parity: zeroed here for the next frame
     uint32_t* host_counts;  // host-mapped: [frustum] totals, [8 + frustum] boundary counts
     uint32_t* draw[YH_K_MAX_FRUSTA];
     uint64_t draw_cap;
-    uint32_t n_chunks, n_tiles, id_base, self_count;
+    uint32_t n_chunks, n_tiles, id_base, epoch;
     uint32_t words;  // visibility words per tile: 64 or 256
 };
 
-__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* s_red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const uint32_t r = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    __syncthreads();
-    return r;
-}
-
-__global__ __launch_bounds__(YH_BLOCK) void k_count(const ExpandArgs x) {
-    __shared__ uint32_t s_red[4];
-    const uint32_t t = blockIdx.x, f = blockIdx.y;
-    const uint32_t c = t * x.words + threadIdx.x;
-    const uint64_t m = (threadIdx.x < x.words && c < x.n_chunks) ? x.vismask[(uint64_t)f * x.n_chunks + c] : 0ull;
-    const uint32_t total = block_sum_256((uint32_t)__popcll(m), s_red);
-    if (threadIdx.x == 0) x.tilecnt[f * x.n_tiles + t] = total;
+__device__ __forceinline__ uint64_t status_word(uint32_t epoch, uint32_t flag, uint32_t value) {
+    return ((uint64_t)epoch << 34) | ((uint64_t)flag << 32) | value;
 }
 
 __global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) {
     __shared__ uint32_t s_red[4];
+    __shared__ uint32_t s_base;
     __shared__ uint32_t s_off[YH_BLOCK];
     __shared__ uint64_t s_mask[YH_BLOCK];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t t = blockIdx.x, f = blockIdx.y;
     const uint64_t* __restrict__ masks = x.vismask + (uint64_t)f * x.n_chunks;
+    uint64_t* __restrict__ status = x.status + (uint64_t)f * x.n_tiles;
     const uint32_t c0 = t * x.words;
     const uint32_t c = c0 + tid;
     const uint64_t m = (tid < x.words && c < x.n_chunks) ? masks[c] : 0ull;
     const uint32_t pc = (uint32_t)__popcll(m);
-    // base = visible entities in the tiles before this one
-    uint32_t part = 0;
-    if (x.self_count) {
-        for (uint32_t i = tid; i < c0; i += YH_BLOCK) part += (uint32_t)__popcll(masks[i]);
-    } else {
-        const uint32_t* __restrict__ cnt = x.tilecnt + (uint64_t)f * x.n_tiles;
-        for (uint32_t i = tid; i < t; i += YH_BLOCK) part += cnt[i];
-    }
-    const uint32_t base = block_sum_256(part, s_red);
     // exclusive scan of the 256 popcounts
     uint32_t inc = pc;
 #pragma unroll
@@ -368,7 +376,46 @@ __global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) {
     for (uint32_t w = 0; w < wv; ++w) wbase += s_red[w];
     s_off[tid] = wbase + inc - pc;
     const uint32_t own = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    if (tid == 0)
+        __hip_atomic_store(&status[t], status_word(x.epoch, t == 0 ? 2u : 1u, own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // base = visible entities in the tiles before this one (decoupled look-back, wave 0)
+    if (wv == 0) {
+        uint32_t base = 0;
+        for (int64_t j = (int64_t)t - 1; j >= 0; j -= 64) {  // wave-uniform
+            const int64_t idx = j - (int64_t)lane;           // lane 0 = nearest predecessor
+            uint32_t flag = 2u, value = 0u;                  // before tile 0: an inclusive prefix of 0
+            if (idx >= 0) {
+                uint64_t st = 0;
+                uint32_t polls = 0;
+                do {
+                    st = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((uint32_t)(st >> 34) != x.epoch && ++polls < YH_LOOKBACK_POLLS);
+                if ((uint32_t)(st >> 34) == x.epoch) {
+                    flag = (uint32_t)(st >> 32) & 3u;
+                    value = (uint32_t)st;
+                } else {  // not published yet: count that tile's words here
+                    const uint32_t w0 = (uint32_t)idx * x.words;
+                    const uint32_t w1 = min(w0 + x.words, x.n_chunks);
+                    flag = 1u;
+                    for (uint32_t w = w0; w < w1; ++w) value += (uint32_t)__popcll(masks[w]);
+                }
+            }
+            const uint64_t is_prefix = __ballot(flag == 2u);
+            const uint32_t stop = is_prefix ? (uint32_t)__builtin_ctzll(is_prefix) : 63u;  // nearest inclusive prefix
+            uint32_t v = lane <= stop ? value : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            base += v;
+            if (is_prefix) break;
+        }
+        if (lane == 0) {
+            s_base = base;
+            if (t > 0)
+                __hip_atomic_store(&status[t], status_word(x.epoch, 2u, base + own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     __syncthreads();
+    const uint32_t base = s_base;
     if (tid == 0) {
         if (t == 0) x.bcount_next[f] = 0;
         if (t + 1 == x.n_tiles) {  // totals of this frustum, to the device (all-gather) and straight to the host

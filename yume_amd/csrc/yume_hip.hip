@@ -35,7 +35,7 @@ struct yh_ctx {
 };
 
 struct LevelGroup {
-    uint32_t lo, hi;  // levels [lo, hi]
+    uint32_t lo, hi;  // levels [lo, hi] of one launch: k_frame_trs if one level, else k_frame_chain
 };
 
 #define YH_TIMING_RING 2048
@@ -53,10 +53,10 @@ struct yh_scene {
     uint8_t* ldirty = nullptr;
     uint8_t* wdirty = nullptr;
     uint32_t* draw[YH_MAX_FRUSTA] = {};
-    uint32_t* counts = nullptr;       // device: 8 visible + 8 boundary totals, then tile counts, then visibility words
-    uint32_t* tilecnt = nullptr;      // inside the counts allocation: [n_frusta][n_tiles]
+    uint32_t* counts = nullptr;       // device: 8 visible + 2 x 8 boundary totals, then look-back words, then visibility words
+    uint64_t* status = nullptr;       // inside the counts allocation: [n_frusta][n_tiles] look-back words of k_expand
     uint64_t* vismask = nullptr;      // inside the counts allocation: [n_frusta][n_chunks]
-    uint64_t vis_bytes = 0;           // bytes of the counts allocation (zeroed at the start of every frame)
+    uint64_t vis_bytes = 0;           // bytes of the counts allocation (zeroed once at creation)
     uint32_t n_chunks = 0, n_tiles = 0, tile_words = 64;
     uint32_t* h_counts = nullptr;     // host-mapped: written by k_expand ([f] totals, [8+f] boundary counts)
     uint32_t* h_counts_dev = nullptr; // device address of h_counts
@@ -66,6 +66,7 @@ struct yh_scene {
     std::vector<uint32_t> level_offsets;
     std::vector<LevelGroup> groups;
     uint32_t max_group_levels = 0;  // 0 = auto
+    std::vector<LevelGroup> explicit_plan;  // yh_scene_set_plan; empty = planner decides
     bool have_hierarchy = false;
     bool frame_pending = false;
     uint32_t last_n_frusta = 0;
@@ -247,18 +248,18 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
         alloc((void**)&s->mesh_id, S * 4);
     }
     for (uint32_t f = 0; f < d->n_frusta; ++f) alloc((void**)&s->draw[f], s->draw_cap * 4);
-    // stage-3 buffers: one allocation = 16 total words | tile counts | visibility words (8-byte aligned);
-    // only the totals and the words need zeroing each frame (tile counts are fully rewritten by k_count)
+    // stage-3 buffers: one allocation = 32 total words | look-back status words | visibility words; zeroed once here,
+    // never per frame (status words are epoch-tagged, visibility words fully rewritten, boundary counters alternate)
     s->n_chunks = (uint32_t)(S / YH_CHUNK);
     s->tile_words = s->n_chunks <= 64u * 4096u ? 64u : (uint32_t)YH_EXPAND_WORDS_MAX;
     s->n_tiles = (s->n_chunks + s->tile_words - 1) / s->tile_words;
     const uint64_t F_alloc = d->n_frusta ? d->n_frusta : 1;
-    const uint64_t tile_words = (F_alloc * s->n_tiles + 1) & ~1ull;
-    s->vis_bytes = (4 * YH_MAX_FRUSTA + tile_words) * 4 + F_alloc * s->n_chunks * 8;
+    s->vis_bytes = 4 * YH_MAX_FRUSTA * 4 + F_alloc * s->n_tiles * 8 + F_alloc * s->n_chunks * 8;
     alloc((void**)&s->counts, s->vis_bytes);
     if (e == hipSuccess) {
-        s->tilecnt = s->counts + 4 * YH_MAX_FRUSTA;  // [0,8) totals, [8,16) and [16,24) boundary counters (two parities)
-        s->vismask = (uint64_t*)(s->tilecnt + tile_words);
+        // [0,8) totals, [8,16) and [16,24) boundary counters (two parities), 8 spare; then status words; then masks
+        s->status = (uint64_t*)(s->counts + 4 * YH_MAX_FRUSTA);
+        s->vismask = s->status + F_alloc * s->n_tiles;
     }
     if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counts, 2 * YH_MAX_FRUSTA * 4, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&s->h_counts_dev, s->h_counts, 0);
@@ -305,33 +306,80 @@ static int sync_scene(yh_scene* s) {
     return YH_OK;
 }
 
-static void plan_groups(yh_scene* s) {
+// Cuts the levels of a TRS scene into launches (Mat4 scenes run one level per launch: the dirty rule needs the
+// parent's flag of this frame).  Measured on MI355X with tools/plan_sweep.py over all 128 cuts of the 8-level
+// 2^k trees of 1M and 12.5M entities (profiles/r01/plan_sweep_*.txt): every dependent launch costs 2-6 us, a chain
+// group costs its deepest entity's dependent walk, so
+//   - levels whose sum fits one residency of the chip (~320k lanes) share one launch, up to 8 levels;
+//   - larger levels go three to a launch (one or two ancestors re-derived per entity beats a launch boundary
+//     and the 64-byte parent gather even at 6M entities per level), the short group first.
+// An explicit plan or grouping (yh_scene_set_plan / yh_scene_set_grouping) replaces this.
+static int plan_groups(yh_scene* s) {
     s->groups.clear();
     const uint32_t L = s->desc.n_levels;
-    const uint32_t maxg = s->max_group_levels ? std::min<uint32_t>(s->max_group_levels, YH_MAX_GROUP) : YH_MAX_GROUP;
-    // automatic: a level joins the running group while the group stays small enough that re-deriving
-    // ancestors is cheaper than another dependent launch (~4 us, i.e. ~10^5 entities of streaming).
-    const uint64_t auto_limit = 768 * 1024;
+    if (!s->explicit_plan.empty()) {
+        s->groups = s->explicit_plan;
+        return YH_OK;
+    }
+    const bool trs = s->desc.local_kind == YH_LOCAL_TRS;
+    auto span = [&](uint32_t lo, uint32_t hi) -> uint64_t { return (uint64_t)s->level_offsets[hi + 1] - s->level_offsets[lo]; };
+    const uint64_t resident = 320 * 1024;
     uint32_t lo = 0;
     while (lo < L) {
         uint32_t hi = lo;
-        while (hi + 1 < L && hi + 1 - lo < maxg) {
-            if (!s->max_group_levels) {
-                const uint64_t merged = (uint64_t)s->level_offsets[hi + 2] - s->level_offsets[lo];
-                if (merged > auto_limit) break;
+        if (!trs || s->max_group_levels == 1) {
+            // one level per launch
+        } else if (s->max_group_levels) {
+            hi = std::min<uint32_t>(L - 1, lo + std::min<uint32_t>(s->max_group_levels, YH_MAX_GROUP) - 1);
+        } else {
+            while (hi + 1 < L && hi + 1 - lo < YH_MAX_GROUP && span(lo, hi + 1) <= resident) ++hi;
+            if (hi == lo && span(lo, lo) > resident / 4) {  // a large level: groups of three, the remainder first
+                uint32_t big_end = lo;  // the run of levels that no longer fit the residency rule
+                while (big_end + 1 < L) ++big_end;
+                const uint32_t run = big_end - lo + 1;
+                const uint32_t take = run % 3 ? run % 3 : 3;
+                hi = lo + take - 1;
             }
-            ++hi;
         }
-        s->groups.push_back({lo, hi});
+        LevelGroup g;
+        g.lo = lo;
+        g.hi = hi;
+        s->groups.push_back(g);
         lo = hi + 1;
     }
+    return YH_OK;
 }
 
 extern "C" int yh_scene_set_grouping(yh_scene* s, uint32_t max_group_levels) {
     if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_scene_set_grouping: scene is NULL");
     ARG_TRY(s->ctx, max_group_levels <= YH_MAX_GROUP, "yh_scene_set_grouping: at most 8 levels per group");
     s->max_group_levels = max_group_levels;
-    if (s->have_hierarchy) plan_groups(s);
+    s->explicit_plan.clear();
+    if (s->have_hierarchy) return plan_groups(s);
+    return YH_OK;
+}
+
+extern "C" int yh_scene_set_plan(yh_scene* s, uint32_t n_groups, const uint32_t* last_level) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_scene_set_plan: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    ARG_TRY(ctx, s->desc.local_kind == YH_LOCAL_TRS, "yh_scene_set_plan: Mat4 scenes run one level per launch");
+    std::vector<LevelGroup> plan;
+    if (n_groups) {
+        ARG_TRY(ctx, last_level, "yh_scene_set_plan: last_level is NULL");
+        uint32_t lo = 0;
+        for (uint32_t i = 0; i < n_groups; ++i) {
+            LevelGroup g;
+            g.lo = lo;
+            g.hi = last_level[i];
+            ARG_TRY(ctx, g.hi >= g.lo && g.hi < s->desc.n_levels && g.hi - g.lo < YH_MAX_GROUP,
+                    "yh_scene_set_plan: groups must be consecutive, non-empty and at most 8 levels each");
+            plan.push_back(g);
+            lo = g.hi + 1;
+        }
+        ARG_TRY(ctx, lo == s->desc.n_levels, "yh_scene_set_plan: the groups must cover every level");
+    }
+    s->explicit_plan = plan;
+    if (s->have_hierarchy) return plan_groups(s);
     return YH_OK;
 }
 
@@ -357,8 +405,7 @@ extern "C" int yh_upload_hierarchy(yh_scene* s, const uint32_t* parent_index, co
     HIP_TRY(ctx, hipMemcpy(s->parent, parent_index, s->n * 4, hipMemcpyHostToDevice));
     s->level_offsets.assign(level_offsets, level_offsets + L + 1);
     s->have_hierarchy = true;
-    plan_groups(s);
-    return YH_OK;
+    return plan_groups(s);
 }
 
 extern "C" int yh_set_root(yh_scene* s, const float root_world[16]) {
@@ -591,52 +638,38 @@ extern "C" int yh_compose(yh_scene* s, float* const planes[16], uint64_t first, 
 }
 
 // ------------------------------------------------------------------------------------------------ frame
-// Dynamic LDS above 64 KiB (8 frusta x 8 KiB of staged indices + control words) needs the per-function opt-in.
-template <typename K>
-static void allow_big_lds(K kernel) {
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-}
-
-template <int G, int BOUNDS, bool HAS_BASE, bool PREFETCH>
-static void launch_trs_g(dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a) {
-    static bool once = (allow_big_lds(k_frame_trs<G, BOUNDS, HAS_BASE, PREFETCH>), true);
-    (void)once;
-    hipLaunchKernelGGL((k_frame_trs<G, BOUNDS, HAS_BASE, PREFETCH>), grid, dim3(YH_BLOCK), lds, st, a);
-}
-
-template <int BOUNDS, bool HAS_BASE, bool PREFETCH>
-static void launch_trs_b(int G, dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a) {
-    switch (G) {
-        case 1: launch_trs_g<1, BOUNDS, HAS_BASE, PREFETCH>(grid, lds, st, a); break;
-        case 2: launch_trs_g<2, BOUNDS, HAS_BASE, PREFETCH>(grid, lds, st, a); break;
-        case 3:
-        case 4: launch_trs_g<4, BOUNDS, HAS_BASE, PREFETCH>(grid, lds, st, a); break;
-        default: launch_trs_g<8, BOUNDS, HAS_BASE, PREFETCH>(grid, lds, st, a); break;
-    }
-}
-
 template <int BOUNDS>
-static void launch_trs(int G, bool has_base, dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a) {
-    static const char* pf_env = getenv("YH_TUNE_PREFETCH");  // tuning knob: 0 / 1, default: on when iters > 1
+static void launch_trs(bool has_base, dim3 grid, hipStream_t st, const FrameArgs& a) {
+    static const char* pf_env = getenv("YH_TUNE_PREFETCH");  // tuning knob: 0 / 1
     const bool prefetch = pf_env ? (atoi(pf_env) != 0) : false;  // measured: occupancy beats the register double buffer
     if (has_base) {
-        if (prefetch) launch_trs_b<BOUNDS, true, true>(G, grid, lds, st, a);
-        else launch_trs_b<BOUNDS, true, false>(G, grid, lds, st, a);
+        if (prefetch) hipLaunchKernelGGL((k_frame_trs<BOUNDS, true, true>), grid, dim3(YH_BLOCK), 0, st, a);
+        else hipLaunchKernelGGL((k_frame_trs<BOUNDS, true, false>), grid, dim3(YH_BLOCK), 0, st, a);
     } else {
-        if (prefetch) launch_trs_b<BOUNDS, false, true>(G, grid, lds, st, a);
-        else launch_trs_b<BOUNDS, false, false>(G, grid, lds, st, a);
+        if (prefetch) hipLaunchKernelGGL((k_frame_trs<BOUNDS, false, true>), grid, dim3(YH_BLOCK), 0, st, a);
+        else hipLaunchKernelGGL((k_frame_trs<BOUNDS, false, false>), grid, dim3(YH_BLOCK), 0, st, a);
     }
+}
+
+template <int BOUNDS, bool HAS_BASE>
+static void launch_chain_g(int G, dim3 grid, hipStream_t st, const FrameArgs& a) {
+    if (G <= 2) hipLaunchKernelGGL((k_frame_chain<2, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a);
+    else if (G <= 3) hipLaunchKernelGGL((k_frame_chain<3, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a);
+    else if (G <= 4) hipLaunchKernelGGL((k_frame_chain<4, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a);
+    else if (G <= 6) hipLaunchKernelGGL((k_frame_chain<6, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((k_frame_chain<8, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a);
+}
+template <int BOUNDS>
+static void launch_chain(int G, bool has_base, dim3 grid, hipStream_t st, const FrameArgs& a) {
+    if (has_base) launch_chain_g<BOUNDS, true>(G, grid, st, a);
+    else launch_chain_g<BOUNDS, false>(G, grid, st, a);
 }
 
 template <int BOUNDS>
 static void launch_mat4(bool has_base, dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
     if (has_base) {
-        static bool once = (allow_big_lds(k_level_mat4<BOUNDS, true>), true);
-        (void)once;
         hipLaunchKernelGGL((k_level_mat4<BOUNDS, true>), grid, dim3(YH_BLOCK), lds, st, a, root_dirty);
     } else {
-        static bool once = (allow_big_lds(k_level_mat4<BOUNDS, false>), true);
-        (void)once;
         hipLaunchKernelGGL((k_level_mat4<BOUNDS, false>), grid, dim3(YH_BLOCK), lds, st, a, root_dirty);
     }
 }
@@ -726,16 +759,23 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
             a.end = s->level_offsets[g.hi + 1];
             if (a.end == a.begin) continue;
             const bool has_base = g.lo > 0;
-            for (uint32_t j = 0; j < YH_MAX_GROUP; ++j)
-                a.lvl_begin[j] = (g.lo + 1 + j <= g.hi) ? s->level_offsets[g.lo + 1 + j] : 0xFFFFFFFFu;
-            a.iters = pick_iters((uint64_t)a.end - a.begin);
-            const size_t lds = lds_bytes(a.iters);
-            const dim3 grid = grid_for(a);
-            const int G = (int)(g.hi - g.lo + 1);
             if (int rc = time_begin(gi)) return rc;
-            if (bounds == 0) launch_trs<0>(G, has_base, grid, lds, st, a);
-            else if (bounds == 1) launch_trs<1>(G, has_base, grid, lds, st, a);
-            else launch_trs<2>(G, has_base, grid, lds, st, a);
+            if (g.hi > g.lo) {
+                a.iters = 1;
+                for (uint32_t j = 0; j < YH_MAX_GROUP; ++j)
+                    a.lvl_begin[j] = (g.lo + 1 + j <= g.hi) ? s->level_offsets[g.lo + 1 + j] : 0xFFFFFFFFu;
+                const dim3 grid = grid_for(a);
+                const int G = (int)(g.hi - g.lo + 1);
+                if (bounds == 0) launch_chain<0>(G, has_base, grid, st, a);
+                else if (bounds == 1) launch_chain<1>(G, has_base, grid, st, a);
+                else launch_chain<2>(G, has_base, grid, st, a);
+            } else {
+                a.iters = pick_iters((uint64_t)a.end - a.begin);
+                const dim3 grid = grid_for(a);
+                if (bounds == 0) launch_trs<0>(has_base, grid, st, a);
+                else if (bounds == 1) launch_trs<1>(has_base, grid, st, a);
+                else launch_trs<2>(has_base, grid, st, a);
+            }
             HIP_TRY(ctx, hipGetLastError());
             if (int rc = time_end()) return rc;
             ++launches;
@@ -770,7 +810,7 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         ExpandArgs x;
         memset(&x, 0, sizeof x);
         x.vismask = s->vismask;
-        x.tilecnt = s->tilecnt;
+        x.status = s->status;
         x.counts = s->counts;
         x.bcount_cur = s->counts + YH_MAX_FRUSTA * (1 + s->bparity);
         x.bcount_next = s->counts + YH_MAX_FRUSTA * (2 - s->bparity);
@@ -782,14 +822,8 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         x.n_tiles = s->n_tiles;
         x.words = s->tile_words;
         x.id_base = s->desc.id_base;
-        static const char* sc_env = getenv("YH_TUNE_SELFCOUNT");  // tuning knob
-        x.self_count = s->n_tiles <= (sc_env ? (uint32_t)atoi(sc_env) : (uint32_t)YH_SELF_COUNT_TILES);
+        x.epoch = (uint32_t)(s->frames % 0x3FFFFFFFull) + 1u;  // never 0: fresh status memory is all zero
         if (int rc = time_begin(YH_MAX_LEVELS - 1)) return rc;
-        if (!x.self_count) {
-            hipLaunchKernelGGL(k_count, dim3(s->n_tiles, n_frusta), dim3(YH_BLOCK), 0, st, x);
-            HIP_TRY(ctx, hipGetLastError());
-            ++launches;
-        }
         hipLaunchKernelGGL(k_expand, dim3(s->n_tiles, n_frusta), dim3(YH_BLOCK), 0, st, x);
         HIP_TRY(ctx, hipGetLastError());
         if (int rc = time_end()) return rc;
