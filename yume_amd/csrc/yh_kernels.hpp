@@ -317,51 +317,69 @@ __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, cons
     }
 }
 
-// ---- stage 3 back end, part 2: single-pass prefix sums + expansion into ordered draw lists ------------------
-// An expand tile is `words` visibility words (64 = 4096 entities, or 256 for scenes beyond 16M entities); one
-// workgroup per (tile, frustum).  The tile's words are prefix-summed through LDS; the tile's base (visible
-// entities in the tiles before it) comes from a decoupled look-back over 64-bit status words
-//     [63:34] frame epoch   [33:32] 1 = tile aggregate, 2 = inclusive prefix   [31:0] value
-// which every workgroup publishes as soon as it knows them (one relaxed agent-scope store; epoch-tagged, so
-// nothing is cleared between frames).  Wave 0 reads the 64 statuses before its tile at a time and stops at the
-// nearest inclusive prefix.  A status that has not appeared after YH_LOOKBACK_POLLS reads is not waited for: the
-// reader popcounts that tile's visibility words itself (they are final before this launch starts), so the kernel
-// terminates whatever order the workgroups are scheduled in.  Then the 4 waves expand the words round-robin, one
-// word per step: lane l emits entity chunk*64+l at rank mbcnt(word).  Ascending entity order, coalesced stores,
-// no atomics on shared addresses, no separate counting launch.
+// ---- stage 3 back end, part 2: prefix sums + expansion into ordered draw lists -----------------------------
+// An expand tile is `words` visibility words (64 = 4096 entities, or 256 for scenes beyond 16M entities).
+// k_count reduces every tile to its visible count; k_expand gives one workgroup to each (tile, frustum): its base
+// is the sum of the tile counts before it (read redundantly: a few thousand L2-resident words, cheaper than a
+// dependent scan launch), the tile's words are prefix-summed through LDS and the 4 waves expand them
+// round-robin, one word per step: lane l emits entity chunk*64+l at rank mbcnt(word).  Ascending entity order,
+// coalesced stores, no atomics.  Scenes of at most YH_SELF_COUNT_TILES tiles skip k_count: every workgroup
+// popcounts the words before its tile itself.
 #define YH_EXPAND_WORDS_MAX 256
-#define YH_LOOKBACK_POLLS 2048
+#define YH_SELF_COUNT_TILES 8
 
 struct ExpandArgs {
     const uint64_t* vismask;
-    uint64_t* status;       // [frustum][n_tiles] look-back words
+    uint32_t* tilecnt;      // [frustum][n_tiles]
     uint32_t* counts;       // device totals [frustum] (input of the RCCL all-gather)
     uint32_t* bcount_cur;   // boundary counters accumulated by this frame's launches
     uint32_t* bcount_next;  // the other parity: zeroed here for the next frame
     uint32_t* host_counts;  // host-mapped: [frustum] totals, [8 + frustum] boundary counts
     uint32_t* draw[YH_K_MAX_FRUSTA];
     uint64_t draw_cap;
-    uint32_t n_chunks, n_tiles, id_base, epoch;
+    uint32_t n_chunks, n_tiles, id_base, self_count;
     uint32_t words;  // visibility words per tile: 64 or 256
 };
 
-__device__ __forceinline__ uint64_t status_word(uint32_t epoch, uint32_t flag, uint32_t value) {
-    return ((uint64_t)epoch << 34) | ((uint64_t)flag << 32) | value;
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* s_red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const uint32_t r = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(YH_BLOCK) void k_count(const ExpandArgs x) {
+    __shared__ uint32_t s_red[4];
+    const uint32_t t = blockIdx.x, f = blockIdx.y;
+    const uint32_t c = t * x.words + threadIdx.x;
+    const uint64_t m = (threadIdx.x < x.words && c < x.n_chunks) ? x.vismask[(uint64_t)f * x.n_chunks + c] : 0ull;
+    const uint32_t total = block_sum_256((uint32_t)__popcll(m), s_red);
+    if (threadIdx.x == 0) x.tilecnt[f * x.n_tiles + t] = total;
 }
 
 __global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) {
     __shared__ uint32_t s_red[4];
-    __shared__ uint32_t s_base;
     __shared__ uint32_t s_off[YH_BLOCK];
     __shared__ uint64_t s_mask[YH_BLOCK];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t t = blockIdx.x, f = blockIdx.y;
     const uint64_t* __restrict__ masks = x.vismask + (uint64_t)f * x.n_chunks;
-    uint64_t* __restrict__ status = x.status + (uint64_t)f * x.n_tiles;
     const uint32_t c0 = t * x.words;
     const uint32_t c = c0 + tid;
     const uint64_t m = (tid < x.words && c < x.n_chunks) ? masks[c] : 0ull;
     const uint32_t pc = (uint32_t)__popcll(m);
+    // base = visible entities in the tiles before this one
+    uint32_t part = 0;
+    if (x.self_count) {
+        for (uint32_t i = tid; i < c0; i += YH_BLOCK) part += (uint32_t)__popcll(masks[i]);
+    } else {
+        const uint32_t* __restrict__ cnt = x.tilecnt + (uint64_t)f * x.n_tiles;
+        for (uint32_t i = tid; i < t; i += YH_BLOCK) part += cnt[i];
+    }
+    const uint32_t base = block_sum_256(part, s_red);
     // exclusive scan of the 256 popcounts
     uint32_t inc = pc;
 #pragma unroll
@@ -376,46 +394,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) {
     for (uint32_t w = 0; w < wv; ++w) wbase += s_red[w];
     s_off[tid] = wbase + inc - pc;
     const uint32_t own = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    if (tid == 0)
-        __hip_atomic_store(&status[t], status_word(x.epoch, t == 0 ? 2u : 1u, own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // base = visible entities in the tiles before this one (decoupled look-back, wave 0)
-    if (wv == 0) {
-        uint32_t base = 0;
-        for (int64_t j = (int64_t)t - 1; j >= 0; j -= 64) {  // wave-uniform
-            const int64_t idx = j - (int64_t)lane;           // lane 0 = nearest predecessor
-            uint32_t flag = 2u, value = 0u;                  // before tile 0: an inclusive prefix of 0
-            if (idx >= 0) {
-                uint64_t st = 0;
-                uint32_t polls = 0;
-                do {
-                    st = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } while ((uint32_t)(st >> 34) != x.epoch && ++polls < YH_LOOKBACK_POLLS);
-                if ((uint32_t)(st >> 34) == x.epoch) {
-                    flag = (uint32_t)(st >> 32) & 3u;
-                    value = (uint32_t)st;
-                } else {  // not published yet: count that tile's words here
-                    const uint32_t w0 = (uint32_t)idx * x.words;
-                    const uint32_t w1 = min(w0 + x.words, x.n_chunks);
-                    flag = 1u;
-                    for (uint32_t w = w0; w < w1; ++w) value += (uint32_t)__popcll(masks[w]);
-                }
-            }
-            const uint64_t is_prefix = __ballot(flag == 2u);
-            const uint32_t stop = is_prefix ? (uint32_t)__builtin_ctzll(is_prefix) : 63u;  // nearest inclusive prefix
-            uint32_t v = lane <= stop ? value : 0u;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            base += v;
-            if (is_prefix) break;
-        }
-        if (lane == 0) {
-            s_base = base;
-            if (t > 0)
-                __hip_atomic_store(&status[t], status_word(x.epoch, 2u, base + own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     __syncthreads();
-    const uint32_t base = s_base;
     if (tid == 0) {
         if (t == 0) x.bcount_next[f] = 0;
         if (t + 1 == x.n_tiles) {  // totals of this frustum, to the device (all-gather) and straight to the host

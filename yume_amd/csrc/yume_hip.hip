@@ -53,8 +53,8 @@ struct yh_scene {
     uint8_t* ldirty = nullptr;
     uint8_t* wdirty = nullptr;
     uint32_t* draw[YH_MAX_FRUSTA] = {};
-    uint32_t* counts = nullptr;       // device: 8 visible + 2 x 8 boundary totals, then look-back words, then visibility words
-    uint64_t* status = nullptr;       // inside the counts allocation: [n_frusta][n_tiles] look-back words of k_expand
+    uint32_t* counts = nullptr;       // device: 8 visible + 2 x 8 boundary totals, then tile counts, then visibility words
+    uint32_t* tilecnt = nullptr;      // inside the counts allocation: [n_frusta][n_tiles]
     uint64_t* vismask = nullptr;      // inside the counts allocation: [n_frusta][n_chunks]
     uint64_t vis_bytes = 0;           // bytes of the counts allocation (zeroed once at creation)
     uint32_t n_chunks = 0, n_tiles = 0, tile_words = 64;
@@ -248,18 +248,19 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
         alloc((void**)&s->mesh_id, S * 4);
     }
     for (uint32_t f = 0; f < d->n_frusta; ++f) alloc((void**)&s->draw[f], s->draw_cap * 4);
-    // stage-3 buffers: one allocation = 32 total words | look-back status words | visibility words; zeroed once here,
-    // never per frame (status words are epoch-tagged, visibility words fully rewritten, boundary counters alternate)
+    // stage-3 buffers: one allocation = 32 total words | tile counts | visibility words (8-byte aligned); zeroed once
+    // here, never per frame (tile counts and visibility words are fully rewritten, boundary counters alternate)
     s->n_chunks = (uint32_t)(S / YH_CHUNK);
-    s->tile_words = s->n_chunks <= 64u * 4096u ? 64u : (uint32_t)YH_EXPAND_WORDS_MAX;
+    // expand tiles: 64 words (4096 entities) keep small scenes parallel; 256 words beyond 8M entities (measured)
+    s->tile_words = s->n_chunks <= 32u * 4096u ? 64u : (uint32_t)YH_EXPAND_WORDS_MAX;
     s->n_tiles = (s->n_chunks + s->tile_words - 1) / s->tile_words;
     const uint64_t F_alloc = d->n_frusta ? d->n_frusta : 1;
-    s->vis_bytes = 4 * YH_MAX_FRUSTA * 4 + F_alloc * s->n_tiles * 8 + F_alloc * s->n_chunks * 8;
+    const uint64_t tile_words = (F_alloc * s->n_tiles + 1) & ~1ull;
+    s->vis_bytes = (4 * YH_MAX_FRUSTA + tile_words) * 4 + F_alloc * s->n_chunks * 8;
     alloc((void**)&s->counts, s->vis_bytes);
     if (e == hipSuccess) {
-        // [0,8) totals, [8,16) and [16,24) boundary counters (two parities), 8 spare; then status words; then masks
-        s->status = (uint64_t*)(s->counts + 4 * YH_MAX_FRUSTA);
-        s->vismask = s->status + F_alloc * s->n_tiles;
+        s->tilecnt = s->counts + 4 * YH_MAX_FRUSTA;  // [0,8) totals, [8,16) and [16,24) boundary counters (two parities)
+        s->vismask = (uint64_t*)(s->tilecnt + tile_words);
     }
     if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counts, 2 * YH_MAX_FRUSTA * 4, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&s->h_counts_dev, s->h_counts, 0);
@@ -810,7 +811,7 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         ExpandArgs x;
         memset(&x, 0, sizeof x);
         x.vismask = s->vismask;
-        x.status = s->status;
+        x.tilecnt = s->tilecnt;
         x.counts = s->counts;
         x.bcount_cur = s->counts + YH_MAX_FRUSTA * (1 + s->bparity);
         x.bcount_next = s->counts + YH_MAX_FRUSTA * (2 - s->bparity);
@@ -822,8 +823,14 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         x.n_tiles = s->n_tiles;
         x.words = s->tile_words;
         x.id_base = s->desc.id_base;
-        x.epoch = (uint32_t)(s->frames % 0x3FFFFFFFull) + 1u;  // never 0: fresh status memory is all zero
+        static const char* sc_env = getenv("YH_TUNE_SELFCOUNT");  // tuning knob
+        x.self_count = s->n_tiles <= (sc_env ? (uint32_t)atoi(sc_env) : (uint32_t)YH_SELF_COUNT_TILES);
         if (int rc = time_begin(YH_MAX_LEVELS - 1)) return rc;
+        if (!x.self_count) {
+            hipLaunchKernelGGL(k_count, dim3(s->n_tiles, n_frusta), dim3(YH_BLOCK), 0, st, x);
+            HIP_TRY(ctx, hipGetLastError());
+            ++launches;
+        }
         hipLaunchKernelGGL(k_expand, dim3(s->n_tiles, n_frusta), dim3(YH_BLOCK), 0, st, x);
         HIP_TRY(ctx, hipGetLastError());
         if (int rc = time_end()) return rc;
