@@ -169,6 +169,8 @@ int yh_timings(yh_scene* s, yh_timing* out);
  * since the previous call (at most 2048 launches are recorded between calls).  enable: 0 = off, 1 = every
  * launch plus the frame, 2 + i = only launch i of the frame (two event records per frame).               */
 int yh_scene_set_kernel_timing(yh_scene* s, int enable);
+/* Sample: record the events on every period-th frame only (an event record stalls the stream for ~3 us). */
+int yh_scene_set_kernel_timing_period(yh_scene* s, uint32_t period);
 int yh_scene_get_groups(yh_scene* s, uint32_t* quads, uint32_t cap, uint32_t* n_groups);
 int yh_scene_get_group_timings(yh_scene* s, float* mean_ms, uint32_t* samples, uint32_t cap);
 /* Hierarchy launches (TRS scenes): levels are cut into groups of consecutive levels, one kernel launch per

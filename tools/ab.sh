@@ -1,13 +1,13 @@
 #!/bin/bash
-# A/B of two builds of libyume_hip.so on the GPU box: tools/ab.sh <base.so> [workloads...]
-# Runs bench.py for each workload with the in-tree library and with <base.so>, one JSON line each into gpurun_out/ab.log
+# A/B of builds of libyume_hip.so on the GPU box: tools/ab.sh "<lib1.so> <lib2.so> ..." [workloads...]
+# Runs bench.py for each workload with the in-tree library and with each given one; summary of one line per run.
 set -e
-BASE=$1; shift
+LIBS=$1; shift
 WL=${@:-cfg2 cfg3 cfg4}
 mkdir -p gpurun_out
 : > gpurun_out/ab.log
 for w in $WL; do
-  for lib in "" "$BASE"; do
+  for lib in "" $LIBS; do
     echo "== $w lib=${lib:-tree}" >> gpurun_out/ab.log
     YUME_HIP_LIB=$lib timeout -k 10 200 python bench.py --workload $w --steps 200 --warmup 20 --no-cpu-baseline >> gpurun_out/ab.log 2>&1
   done

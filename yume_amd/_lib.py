@@ -106,6 +106,7 @@ SIGNATURES = {
     "yh_compose": (_int, [_vp, _vp, _u64, _u64]),
     "yh_timings": (_int, [_vp, C.POINTER(Timing)]),
     "yh_scene_set_kernel_timing": (_int, [_vp, _int]),
+    "yh_scene_set_kernel_timing_period": (_int, [_vp, _u32]),
     "yh_scene_set_plan": (_int, [_vp, _u32, _vp]),
     "yh_scene_get_groups": (_int, [_vp, _vp, _u32, C.POINTER(_u32)]),
     "yh_scene_get_group_timings": (_int, [_vp, _vp, _vp, _u32]),

@@ -243,7 +243,9 @@ class Scene:
         return {"last_frame_ms": t.last_frame_ms, "last_kernel_ms": t.last_kernel_ms, "n_launches": t.n_launches,
                 "n_groups": t.n_groups, "frames": t.frames}
 
-    def set_kernel_timing(self, enable):
+    def set_kernel_timing(self, enable, period=1):
+        """0 off, 1 every launch + frame, 2+i only launch i; events on every period-th frame."""
+        self._ck(L.lib().yh_scene_set_kernel_timing_period(self._h, int(period)))
         self._ck(L.lib().yh_scene_set_kernel_timing(self._h, int(enable)))
 
     def groups(self):

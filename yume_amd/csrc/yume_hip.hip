@@ -79,6 +79,7 @@ struct yh_scene {
     uint32_t last_launches = 0;
     bool kernel_timing = false;
     int timing_only = -1;  // >= 0: only this launch index gets events (and no frame events)
+    uint32_t timing_period = 1;  // events on every timing_period-th frame only
     bool frame_timed = false;
     std::vector<hipEvent_t> kev;  // YH_TIMING_RING pairs, lazily created
     std::vector<uint32_t> kev_group;
@@ -730,7 +731,7 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         return dim3(cdiv((uint64_t)fa.end - (fa.begin & ~63u), (uint64_t)fa.iters * YH_BLOCK));
     };
 
-    const bool frame_events = s->kernel_timing && s->timing_only < 0;
+    const bool frame_events = s->kernel_timing && s->timing_only < 0 && (s->frames % s->timing_period == 0);
     if (frame_events) HIP_TRY(ctx, hipEventRecord(s->ev0, st));
     uint32_t launches = 0;
     if (s->kernel_timing)
@@ -738,7 +739,8 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
 
     bool timing_this = false;
     auto time_begin = [&](uint32_t group) -> int {
-        timing_this = s->kernel_timing && s->kev_used < YH_TIMING_RING && (s->timing_only < 0 || (uint32_t)s->timing_only == group);
+        timing_this = s->kernel_timing && s->kev_used < YH_TIMING_RING && (s->timing_only < 0 || (uint32_t)s->timing_only == group) &&
+                      (s->frames % s->timing_period == 0);
         if (timing_this) {
             s->kev_group[s->kev_used] = group;
             HIP_TRY(ctx, hipEventRecord(s->kev[2 * s->kev_used], st));
@@ -905,6 +907,12 @@ extern "C" int yh_timings(yh_scene* s, yh_timing* out) {
 }
 
 // Not part of the reference-facing boundary: per-launch HIP-event timing for the measurement harness.
+extern "C" int yh_scene_set_kernel_timing_period(yh_scene* s, uint32_t period) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_scene_set_kernel_timing_period: scene is NULL");
+    s->timing_period = period ? period : 1;
+    return YH_OK;
+}
+
 extern "C" int yh_scene_set_kernel_timing(yh_scene* s, int enable) {
     if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_scene_set_kernel_timing: scene is NULL");
     s->kernel_timing = enable != 0;
