@@ -724,7 +724,8 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     auto pick_iters = [](uint64_t n_launch) -> uint32_t {
         static const char* it_env = getenv("YH_TUNE_ITERS");  // tuning knob
         if (it_env) return (uint32_t)std::min<int>(std::max<int>(atoi(it_env), 1), YH_MAX_ITERS);
-        return n_launch >= 256 * 1024 ? 2u : 1u;  // measured: 2 slices per workgroup once the grid fills the chip
+        (void)n_launch;
+        return 1u;  // measured with streaming loads/stores: one slice per workgroup wins at every size
     };
     auto lds_bytes = [&](uint32_t) -> size_t { return 0; };
     auto grid_for = [&](const FrameArgs& fa) -> dim3 {
