@@ -126,6 +126,35 @@ def cpu_baseline(args, wl, n, lo, parent, planes, seconds):
     return out
 
 
+def kernel_symbol(levels_in_group, bounds, has_base):
+    """Name rocprofv3 reports for the launch of a level group (yume_hip.hip launch_trs / launch_chain)."""
+    hb = "true" if has_base else "false"
+    if levels_in_group == 1:
+        return f"void k_frame_trs<{bounds}, {hb}, false>(FrameArgs)"
+    g = next(x for x in (2, 3, 4, 6, 8) if levels_in_group <= x)
+    return f"void k_frame_chain<{g}, {bounds}, {hb}>(FrameArgs)"
+
+
+def profiled_traffic(workload, symbol):
+    """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC passes (profiles/r*/, newest round first):
+    2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 FETCH_SIZE correction as calibrated in profiles/r01/SUMMARY.md."""
+    import csv
+    import glob
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for d in sorted(glob.glob(os.path.join(here, "profiles", "r*")), reverse=True):
+        vals = {}
+        for kind in ("fetch", "write"):
+            f = os.path.join(d, f"{workload}_pmc_{kind}_mean_kib_per_dispatch.csv")
+            if os.path.exists(f):
+                for r in csv.DictReader(open(f)):
+                    if r["kernel"] == symbol:
+                        vals[kind] = float(r["mean_KiB_per_dispatch"])
+        if len(vals) == 2:
+            return (2 * vals["fetch"] + vals["write"]) * 1024.0, os.path.relpath(d, here)
+    return None, None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -249,10 +278,13 @@ def main():
         first, end = int(groups[g][2]), int(groups[g][3])
         b = algorithmic_bytes(wl, lo, parent, first, end, vis_sum)
         achieved = b / (ms[g] * 1e-3) / 1e9
+        sym = kernel_symbol(int(groups[g][1]) - int(groups[g][0]) + 1, wl["bounds"], int(groups[g][0]) > 0)
+        traffic, traffic_src = profiled_traffic(args.workload, sym) if n == wl["n"] // (world_size if wl["scaling"] == "strong" else 1) else (None, None)
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-            "kernel": f"k_frame_trs levels {int(groups[g][0])}..{int(groups[g][1])}",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "kernel_symbol": sym,
+            "kernel": f"{sym.split('<')[0].replace('void ', '')} levels {int(groups[g][0])}..{int(groups[g][1])}",
             "kernel_entities": end - first, "kernel_ms": round(float(ms[g]), 5), "kernel_samples": int(samples[g]), "kernel_sampling_period": period,
             "algorithmic_bytes_per_launch": b, "algorithmic_bytes_per_entity": round(b / (end - first), 2),
             "launch_ms_all_calibration": [round(float(x), 5) for x in ms_all[: len(groups)]],
