@@ -159,6 +159,19 @@ int yh_get_draw_list(yh_scene* s, uint32_t frustum, uint32_t* out, uint64_t cap,
 int yh_download_world_soa(yh_scene* s, float* const planes[16], uint64_t first, uint64_t count);
 int yh_download_world_aos68(yh_scene* s, void* column, uint64_t first, uint64_t count);
 int yh_download_local_aos68(yh_scene* s, void* column, uint64_t first, uint64_t count);
+/* ---- sparse rows and change tracking (Mat4 scenes) -------------------------------------------
+ * The onSet hooks (transform.zig:46-51, 92-97) are the only writers of `dirty`, so the rows a host changed since
+ * the last frame are known to it: yh_upload_*_rows_aos68 sends just those (row r belongs to entity slots[r]).
+ * With yh_scene_track_changes on, every yh_frame also records which rows it recomputed or found edited (dirty
+ * before the PostTransformSystem sweep); yh_download_changed_aos68 returns their slots (ascending) and both rows,
+ * dirty bytes cleared — what the CPU systems would have left in those rows; all other rows are untouched by the
+ * frame.  cap too small: YH_ERR_CAPACITY with *written = rows needed.  Any of the three outputs may be NULL.  */
+int yh_upload_local_rows_aos68(yh_scene* s, const uint32_t* slots, const void* rows, uint64_t count);
+int yh_upload_world_rows_aos68(yh_scene* s, const uint32_t* slots, const void* rows, uint64_t count);
+int yh_scene_track_changes(yh_scene* s, int enable);
+int yh_get_changed_count(yh_scene* s, uint64_t* n_changed);
+int yh_download_changed_aos68(yh_scene* s, uint32_t* slots, void* world_rows, void* local_rows, uint64_t cap,
+                              uint64_t* written);
 /* Stage 1 alone: Mat4.compose over a range, result as 16 SoA planes on the host (testing aid).          */
 int yh_compose(yh_scene* s, float* const planes[16], uint64_t first, uint64_t count);
 

@@ -28,7 +28,9 @@
  *              kind 3: re-parent under entity index bits(m[0]) (ecs.zig:470-477 setParent)
  * out.bin:   per frame: world rows n x 68 B, local rows n x 68 B (all zero for deleted entities), u64 batches,
  *            u64 rows_seen, u32 up_fields_shared; GPU build + YFH2: then per frustum u32 count, u32 entity_index[count]
- *            (GPU build: batches = slot-order rebuilds so far, rows_seen = entities in the device scene)
+ *            (GPU build: batches = slot-order rebuilds so far, rows_seen = entities in the device scene), then
+ *            u64 rows_up, u64 rows_down = 68-byte rows that crossed PCIe in the frame.  GPU build, env YFH_PLAIN=1:
+ *            whole columns both ways every frame instead of the incremental mode.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -187,6 +189,7 @@ int main(int argc, char** argv) {
         for (uint32_t e = 0; e < n; ++e) GpuTransformCullSystem_setBounds(gpu, ent[e], bounds + 6 * (size_t)e);
         GpuTransformCullSystem_setFrusta(gpu, planes, n_frusta);
     }
+    if (getenv("YFH_PLAIN")) GpuTransformCullSystem_setIncremental(gpu, 0);
     ecs_entity_t* vis = malloc(sizeof(ecs_entity_t) * n);
     uint32_t* vis_idx = malloc(sizeof(uint32_t) * n);
 #else
@@ -267,6 +270,9 @@ int main(int argc, char** argv) {
             fwrite(&c32, 4, 1, fout);
             fwrite(vis_idx, 4, c32, fout);
         }
+        uint64_t traffic[2];
+        GpuTransformCullSystem_lastTraffic(gpu, &traffic[0], &traffic[1]);
+        fwrite(traffic, 8, 2, fout);
 #endif
     }
 #ifdef USE_GPU_SYSTEM

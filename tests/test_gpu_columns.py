@@ -116,6 +116,82 @@ def test_dirty_frames_match_reference_system(ctx, oracle):
         step("frame 6 (root moved)")
 
 
+def test_sparse_rows_and_change_tracking(ctx, oracle):
+    """only dirty rows go up, only rows the frame touched come back.  A host mirror patched with the
+    returned rows must equal the oracle's full columns after every frame, and untouched frames return nothing."""
+    from yume_amd import Scene, _lib
+
+    n = 80_000
+    lo, par, bounds, local, world = build(oracle, n, 7)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    root = oracle.identity68()
+    rng = np.random.default_rng(5)
+    with Scene(ctx, n, n_levels=7, n_frusta=1, local_kind=_lib.YH_LOCAL_MAT4) as s:
+        with pytest.raises(_lib.YumeHipError) as e:
+            s.changed()
+        assert e.value.code == _lib.YH_ERR_STATE  # tracking is off
+        s.upload_hierarchy(par, lo)
+        s.upload_aabb(np.ascontiguousarray(bounds[:, 0:3].T), np.ascontiguousarray(bounds[:, 3:6].T))
+        s.upload_local_aos68(local)
+        s.upload_world_aos68(world)
+        s.track_changes(True)
+        mirror_w, mirror_l = world.copy(), local.copy()  # what the host (flecs) holds
+
+        def step(tag, expect_changed=None):
+            before_w, before_l = world.copy(), local.copy()
+            oracle.frame_aos68(world, local, par, lo, root)
+            s.frame(planes, flags=0)
+            slots, rw, rl = s.changed()
+            touched = np.flatnonzero(before_w["dirty"] | before_l["dirty"] | (world["dirty"] != before_w["dirty"]) |
+                                     (world["m"] != before_w["m"]).any(axis=1) | (local["m"] != before_l["m"]).any(axis=1))
+            oracle_changed = np.flatnonzero(np.any(world["m"].view(np.uint32) != before_w["m"].view(np.uint32), axis=1) |
+                                            np.any(local["m"].view(np.uint32) != before_l["m"].view(np.uint32), axis=1))
+            assert np.all(np.diff(slots.astype(np.int64)) > 0), tag
+            assert np.isin(oracle_changed, slots).all(), f"{tag}: a changed row is missing from the list"
+            assert np.isin(touched, slots).all(), tag
+            if expect_changed is not None:
+                assert slots.size == expect_changed, f"{tag}: {slots.size} rows returned"
+            mirror_w[slots] = rw
+            mirror_l[slots] = rl
+            mirror_w["dirty"] = 0  # PostTransformSystem on the host side of a row that was dirty is in the returned rows;
+            mirror_l["dirty"] = 0  # rows not returned were clean already
+            oracle_w, oracle_l = world.copy(), local.copy()
+            with np.errstate(all="ignore"):
+                assert_same_values(mirror_w["m"], oracle_w["m"], f"{tag}: world mirror")
+                assert_same_values(mirror_l["m"], oracle_l["m"], f"{tag}: local mirror")
+            assert not rw["dirty"].any() and not rl["dirty"].any()
+            # and the device columns themselves agree
+            assert_same_values(s.world_aos68()["m"], oracle_w["m"], f"{tag}: device world")
+
+        step("frame 0 (everything dirty)", expect_changed=n)
+        step("frame 1 (nothing dirty)", expect_changed=0)
+
+        idx = np.unique(rng.integers(0, n, 400)).astype(np.uint32)
+        for e_ in idx:
+            local["m"][e_] = oracle.compose(rng.uniform(-5, 5, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+        local["dirty"][idx] = 1
+        s.upload_local_rows(idx, local[idx])
+        step("frame 2 (sparse local edits)")
+
+        idx = np.unique(rng.integers(int(lo[1]), n, 250)).astype(np.uint32)
+        for e_ in idx:
+            world["m"][e_] = oracle.compose(rng.uniform(-50, 50, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+        world["dirty"][idx] = 1
+        s.upload_world_rows(idx[::-1], world[idx[::-1]])  # any order
+        step("frame 3 (sparse world edits)")
+        step("frame 4 (nothing dirty)", expect_changed=0)
+
+        leaf = np.array([n - 1], np.uint32)  # one leaf: exactly one row comes back
+        local["m"][leaf] = oracle.compose([1, 1, 1], [0, 0, 0, 1], [1, 1, 1])
+        local["dirty"][leaf] = 1
+        s.upload_local_rows(leaf, local[leaf])
+        step("frame 5 (one leaf)", expect_changed=1)
+
+        with pytest.raises(_lib.YumeHipError) as e:
+            s.upload_local_rows(np.array([n], np.uint32), local[:1])
+        assert e.value.code == _lib.YH_ERR_BAD_ARG
+
+
 def test_mat4_all_dirty_equals_trs_path(ctx, oracle):
     """The same scene through both device representations gives the same world matrices and draw lists."""
     from yume_amd import Scene, _lib

@@ -41,7 +41,7 @@ def write_scene(path, lo, parent, local_m, root_m, planes, bounds, frames):
                 f.write(np.ascontiguousarray(m, np.float32).tobytes())
 
 
-def read_out(path, n, n_frames, n_frusta, T68):
+def read_out(path, n, n_frames, n_frusta, T68, gpu=False):
     raw = open(path, "rb").read()
     res, pos = [], 0
     for _ in range(n_frames):
@@ -56,6 +56,9 @@ def read_out(path, n, n_frames, n_frusta, T68):
             (c,) = struct.unpack_from("<I", raw, pos)
             vis.append(np.frombuffer(raw, np.uint32, c, pos + 4).copy())
             pos += 4 + 4 * c
+        if gpu:
+            vis.append(struct.unpack_from("<QQ", raw, pos))  # last element: (rows up, rows down)
+            pos += 16
         res.append((w, l, a, b, vis))
     assert pos == len(raw)
     return res
@@ -67,8 +70,9 @@ def reparent_arg(index):
     return m
 
 
+@pytest.mark.parametrize("plain", [False, True], ids=["incremental", "whole-columns"])
 @pytest.mark.parametrize("n,levels", [(10_000, 1), (4096, 8), (50_000, 6)])
-def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, levels):
+def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, levels, plain):
     rng = np.random.default_rng(n + levels)
     lo = oracle.synth_level_offsets(n, levels)
     par = oracle.synth_parents(lo)
@@ -100,9 +104,13 @@ def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, le
     scene, out_c, out_g = tmp_path / "scene.bin", tmp_path / "cpu.bin", tmp_path / "gpu.bin"
     write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
     subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
-    subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300)
+    env = dict(os.environ)
+    env.pop("YFH_PLAIN", None)
+    if plain:
+        env["YFH_PLAIN"] = "1"
+    subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
     cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
-    gpu = read_out(out_g, n, len(frames), planes.shape[0], oracle.T68)
+    gpu = read_out(out_g, n, len(frames), planes.shape[0], oracle.T68, gpu=True)
 
     alive = np.ones(n, bool)
     rebuilds_before = 0
@@ -119,6 +127,15 @@ def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, le
         structural = any(kind in (2, 3) for _e, kind, _m in frames[fi])
         assert rebuilds == rebuilds_before + (1 if (fi == 0 or structural) else 0), f"frame {fi}: rebuild count"
         rebuilds_before = rebuilds
+        up, down = vis[-1]
+        if plain:
+            assert up == down == 2 * g_rows, f"frame {fi}: whole columns travel in plain mode"
+        elif not (fi == 0 or structural):
+            n_edits = len(frames[fi])
+            assert up <= n_edits, f"frame {fi}: {up} rows uploaded for {n_edits} edits"
+            if n_edits == 0:
+                assert up == 0 and down == 0, f"frame {fi}: nothing moved, yet rows crossed PCIe"
+            assert down < 2 * g_rows or fi == 5  # only the re-rooting frame touches every row
         idx = np.flatnonzero(alive)
         exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[idx]), np.ascontiguousarray(bounds[idx]), planes)
         for f in range(planes.shape[0]):

@@ -107,6 +107,11 @@ SIGNATURES = {
     "yh_timings": (_int, [_vp, C.POINTER(Timing)]),
     "yh_scene_set_kernel_timing": (_int, [_vp, _int]),
     "yh_scene_set_kernel_timing_period": (_int, [_vp, _u32]),
+    "yh_upload_local_rows_aos68": (_int, [_vp, _vp, _vp, _u64]),
+    "yh_upload_world_rows_aos68": (_int, [_vp, _vp, _vp, _u64]),
+    "yh_scene_track_changes": (_int, [_vp, _int]),
+    "yh_get_changed_count": (_int, [_vp, C.POINTER(_u64)]),
+    "yh_download_changed_aos68": (_int, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     "yh_scene_set_plan": (_int, [_vp, _u32, _vp]),
     "yh_scene_get_groups": (_int, [_vp, _vp, _u32, C.POINTER(_u32)]),
     "yh_scene_get_group_timings": (_int, [_vp, _vp, _vp, _u32]),

@@ -217,6 +217,33 @@ class Scene:
         self._ck(L.lib().yh_download_local_aos68(self._h, _ptr(out), first, count))
         return out
 
+    # ---- sparse rows / change tracking (Mat4 scenes) ----
+    def upload_local_rows(self, slots, rows):
+        slots = np.ascontiguousarray(slots, np.uint32)
+        rows = np.ascontiguousarray(rows, T68)
+        assert slots.shape == rows.shape
+        self._ck(L.lib().yh_upload_local_rows_aos68(self._h, _ptr(slots), _ptr(rows), slots.size))
+
+    def upload_world_rows(self, slots, rows):
+        slots = np.ascontiguousarray(slots, np.uint32)
+        rows = np.ascontiguousarray(rows, T68)
+        assert slots.shape == rows.shape
+        self._ck(L.lib().yh_upload_world_rows_aos68(self._h, _ptr(slots), _ptr(rows), slots.size))
+
+    def track_changes(self, enable=True):
+        self._ck(L.lib().yh_scene_track_changes(self._h, int(bool(enable))))
+
+    def changed(self):
+        """(slots, world rows, local rows) the last frame recomputed or found edited; ascending slots."""
+        n = C.c_uint64()
+        self._ck(L.lib().yh_get_changed_count(self._h, C.byref(n)))
+        slots = np.zeros(n.value, np.uint32)
+        w = np.zeros(n.value, T68)
+        l = np.zeros(n.value, T68)
+        wr = C.c_uint64()
+        self._ck(L.lib().yh_download_changed_aos68(self._h, _ptr(slots), _ptr(w), _ptr(l), n.value, C.byref(wr)))
+        return slots, w, l
+
     def compose(self, first=0, count=None):
         count = self.n - first if count is None else count
         out = np.empty((16, count), np.float32)

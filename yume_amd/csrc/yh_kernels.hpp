@@ -421,6 +421,23 @@ __global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) {
     }
 }
 
+// The same sweep when changes are tracked (yh_scene_track_changes): one wave per 64-entity chunk first publishes
+// the ballot of "LocalTransform.dirty or WorldTransform.dirty" — every row this frame recomputed or found edited —
+// as the chunk's word of the change mask, then clears both flags.  k_count / k_expand turn the mask into the
+// ascending list of changed slots, exactly as they do for a frustum.
+__global__ __launch_bounds__(YH_BLOCK) void k_sweep_dirty(uint8_t* __restrict__ ld, uint8_t* __restrict__ wd, uint32_t n,
+                                                          uint64_t* __restrict__ words) {
+    const uint64_t e = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;  // the grid covers whole chunks
+    const bool in = e < n;
+    const bool changed = in && ((ld[e] | wd[e]) != 0);
+    const uint64_t m = __ballot(changed);
+    if ((threadIdx.x & 63u) == 0) words[e >> 6] = m;
+    if (in) {
+        ld[e] = 0;
+        wd[e] = 0;
+    }
+}
+
 // PostWorldTransform + PostLocalTransform (PostTransformSystem.zig:31-35): both dirty planes to 0.
 __global__ __launch_bounds__(YH_BLOCK) void k_clear_dirty(uint32_t* __restrict__ ld, uint32_t* __restrict__ wd,
                                                           uint64_t n_words) {
@@ -475,9 +492,10 @@ __global__ __launch_bounds__(YH_BLOCK) void k_compose(const float* __restrict__ 
 // flecs column import/export: 68-byte rows {f32 m[16]; u8 dirty; u8 pad[3]} (transform.zig:8-12) <-> chunked
 // planes.  A workgroup moves 256 rows = 4352 dwords with coalesced dword accesses on the AoS side and
 // transposes through LDS; the row stride of 17 dwords is odd, so both LDS phases are bank-conflict free.
+// `slots` (optional): row r goes to / comes from entity slots[r] instead of first + r (sparse dirty rows).
 __global__ __launch_bounds__(YH_BLOCK) void k_aos68_to_soa(const uint32_t* __restrict__ rows, uint64_t count,
                                                            float* __restrict__ arr, uint8_t* __restrict__ dirty,
-                                                           uint64_t first) {
+                                                           uint64_t first, const uint32_t* __restrict__ slots) {
     __shared__ uint32_t tile[YH_BLOCK * 17];
     const uint64_t r0 = (uint64_t)blockIdx.x * YH_BLOCK;
     const uint64_t nrows = (count - r0 < YH_BLOCK) ? (count - r0) : YH_BLOCK;
@@ -485,7 +503,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_aos68_to_soa(const uint32_t* __res
     for (uint32_t i = threadIdx.x; i < ndw; i += YH_BLOCK) tile[i] = rows[r0 * 17 + i];
     __syncthreads();
     if (threadIdx.x < nrows) {
-        const uint32_t e = (uint32_t)(first + r0 + threadIdx.x);
+        const uint32_t e = slots ? slots[r0 + threadIdx.x] : (uint32_t)(first + r0 + threadIdx.x);
         const uint64_t off = eoff<16>(e);
 #pragma unroll
         for (int q = 0; q < 16; ++q) ste(arr, off, q, __uint_as_float(tile[threadIdx.x * 17 + q]));
@@ -495,12 +513,13 @@ __global__ __launch_bounds__(YH_BLOCK) void k_aos68_to_soa(const uint32_t* __res
 
 __global__ __launch_bounds__(YH_BLOCK) void k_soa_to_aos68(const float* __restrict__ arr,
                                                            const uint8_t* __restrict__ dirty, uint64_t first,
-                                                           uint64_t count, uint32_t* __restrict__ rows) {
+                                                           uint64_t count, uint32_t* __restrict__ rows,
+                                                           const uint32_t* __restrict__ slots) {
     __shared__ uint32_t tile[YH_BLOCK * 17];
     const uint64_t r0 = (uint64_t)blockIdx.x * YH_BLOCK;
     const uint64_t nrows = (count - r0 < YH_BLOCK) ? (count - r0) : YH_BLOCK;
     if (threadIdx.x < nrows) {
-        const uint32_t e = (uint32_t)(first + r0 + threadIdx.x);
+        const uint32_t e = slots ? slots[first + r0 + threadIdx.x] : (uint32_t)(first + r0 + threadIdx.x);
         const uint64_t off = eoff<16>(e);
 #pragma unroll
         for (int q = 0; q < 16; ++q) tile[threadIdx.x * 17 + q] = __float_as_uint(lde(arr, off, q));

@@ -61,6 +61,15 @@ struct yh_scene {
     uint32_t* h_counts = nullptr;     // host-mapped: written by k_expand ([f] totals, [8+f] boundary counts)
     uint32_t* h_counts_dev = nullptr; // device address of h_counts
     uint32_t bparity = 0;             // which of the two boundary-counter sets this frame uses
+    // change tracking (Mat4 scenes, yh_scene_track_changes): mask of rows a frame touched -> ascending slot list
+    bool track = false;
+    uint32_t* chg = nullptr;          // device: 32 count words | tile counts | mask words (one allocation)
+    uint32_t* chg_tilecnt = nullptr;
+    uint64_t* chg_words = nullptr;
+    uint32_t* chg_list = nullptr;     // device: changed slots of the last frame
+    uint32_t* h_chg = nullptr;        // host-mapped totals written by k_expand
+    uint32_t* h_chg_dev = nullptr;
+    bool chg_valid = false;           // a tracked frame has run since tracking was enabled
     void* staging = nullptr;          // device staging for AoS68 import/export
     uint64_t staging_bytes = 0;
     std::vector<uint32_t> level_offsets;
@@ -193,7 +202,7 @@ static void scene_free(yh_scene* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     void* ptrs[] = {s->trs, s->lmat, s->world, s->parent, s->bounds, s->mesh_id, s->ldirty, s->wdirty, s->counts,
-                    s->staging, s->d_all_counts};
+                    s->staging, s->d_all_counts, s->chg, s->chg_list};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (uint32_t f = 0; f < YH_MAX_FRUSTA; ++f) {
@@ -201,6 +210,7 @@ static void scene_free(yh_scene* s) {
         if (s->gathered[f]) (void)hipFree(s->gathered[f]);
     }
     if (s->h_counts) (void)hipHostFree(s->h_counts);
+    if (s->h_chg) (void)hipHostFree(s->h_chg);
     if (s->h_all_counts) (void)hipHostFree(s->h_all_counts);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -542,23 +552,30 @@ static int ensure_staging(yh_scene* s, uint64_t bytes) {
 // rows per staging chunk of the AoS68 import/export (68 MB of staging)
 #define YH_AOS_CHUNK (1u << 20)
 
-static int upload_aos68(yh_scene* s, const void* column, uint64_t first, uint64_t count, float* planes, uint8_t* dirty) {
+// host_slots (optional): row r belongs to entity host_slots[r] (sparse upload) instead of first + r
+static int upload_aos68(yh_scene* s, const void* column, uint64_t first, uint64_t count, float* planes, uint8_t* dirty,
+                        const uint32_t* host_slots = nullptr) {
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     if (int rc = sync_scene(s)) return rc;
-    if (int rc = ensure_staging(s, (uint64_t)std::min<uint64_t>(count ? count : 1, YH_AOS_CHUNK) * 68)) return rc;
+    const uint64_t chunk_rows = std::min<uint64_t>(count ? count : 1, YH_AOS_CHUNK);
+    if (int rc = ensure_staging(s, chunk_rows * 72)) return rc;  // rows, then (sparse) their slots
+    uint32_t* d_slots = host_slots ? (uint32_t*)((char*)s->staging + chunk_rows * 68) : nullptr;
     const char* src = (const char*)column;
     for (uint64_t done = 0; done < count; done += YH_AOS_CHUNK) {
         const uint64_t c = std::min<uint64_t>(YH_AOS_CHUNK, count - done);
         HIP_TRY(s->ctx, hipMemcpyAsync(s->staging, src + done * 68, c * 68, hipMemcpyHostToDevice, s->ctx->stream));
+        if (host_slots) HIP_TRY(s->ctx, hipMemcpyAsync(d_slots, host_slots + done, c * 4, hipMemcpyHostToDevice, s->ctx->stream));
         hipLaunchKernelGGL(k_aos68_to_soa, dim3(cdiv(c, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream,
-                           (const uint32_t*)s->staging, c, planes, dirty, first + done);
+                           (const uint32_t*)s->staging, c, planes, dirty, first + done, (const uint32_t*)d_slots);
         HIP_TRY(s->ctx, hipGetLastError());
         HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
     }
     return YH_OK;
 }
 
-static int download_aos68(yh_scene* s, void* column, uint64_t first, uint64_t count, const float* planes, const uint8_t* dirty) {
+// dev_slots (optional): row first + r comes from entity dev_slots[first + r] (a device-resident slot list)
+static int download_aos68(yh_scene* s, void* column, uint64_t first, uint64_t count, const float* planes, const uint8_t* dirty,
+                          const uint32_t* dev_slots = nullptr) {
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     if (int rc = sync_scene(s)) return rc;
     if (int rc = ensure_staging(s, (uint64_t)std::min<uint64_t>(count ? count : 1, YH_AOS_CHUNK) * 68)) return rc;
@@ -566,7 +583,7 @@ static int download_aos68(yh_scene* s, void* column, uint64_t first, uint64_t co
     for (uint64_t done = 0; done < count; done += YH_AOS_CHUNK) {
         const uint64_t c = std::min<uint64_t>(YH_AOS_CHUNK, count - done);
         hipLaunchKernelGGL(k_soa_to_aos68, dim3(cdiv(c, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream, planes, dirty,
-                           first + done, c, (uint32_t*)s->staging);
+                           first + done, c, (uint32_t*)s->staging, dev_slots);
         HIP_TRY(s->ctx, hipGetLastError());
         HIP_TRY(s->ctx, hipMemcpyAsync(dst + done * 68, s->staging, c * 68, hipMemcpyDeviceToHost, s->ctx->stream));
         HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
@@ -598,6 +615,78 @@ extern "C" int yh_download_local_aos68(yh_scene* s, void* column, uint64_t first
     ARG_TRY(s->ctx, column, "yh_download_local_aos68: column is NULL");
     if (s->desc.local_kind != YH_LOCAL_MAT4) return fail(s->ctx, YH_ERR_STATE, "yh_download_local_aos68: scene holds TRS locals");
     return download_aos68(s, column, first, count, s->lmat, s->ldirty);
+}
+
+// ---- sparse rows and change tracking (only dirty rows cross PCIe) ---------------------------------
+static int upload_rows(yh_scene* s, const char* who, const uint32_t* slots, const void* rows, uint64_t count, float* planes,
+                       uint8_t* dirty) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "%s: scene is NULL", who);
+    if (count == 0) return YH_OK;
+    if (!slots || !rows) return fail(s->ctx, YH_ERR_BAD_ARG, "%s: NULL argument", who);
+    if (!planes) return fail(s->ctx, YH_ERR_STATE, "%s: scene holds TRS locals", who);
+    for (uint64_t i = 0; i < count; ++i)
+        if (slots[i] >= s->n) return fail(s->ctx, YH_ERR_BAD_ARG, "%s: slot %u at %llu >= n_entities", who, slots[i], (unsigned long long)i);
+    return upload_aos68(s, rows, 0, count, planes, dirty, slots);
+}
+
+extern "C" int yh_upload_local_rows_aos68(yh_scene* s, const uint32_t* slots, const void* rows, uint64_t count) {
+    return upload_rows(s, "yh_upload_local_rows_aos68", slots, rows, count, s ? s->lmat : nullptr, s ? s->ldirty : nullptr);
+}
+
+extern "C" int yh_upload_world_rows_aos68(yh_scene* s, const uint32_t* slots, const void* rows, uint64_t count) {
+    return upload_rows(s, "yh_upload_world_rows_aos68", slots, rows, count, s ? s->world : nullptr, s ? s->wdirty : nullptr);
+}
+
+extern "C" int yh_scene_track_changes(yh_scene* s, int enable) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_scene_track_changes: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    if (s->desc.local_kind != YH_LOCAL_MAT4)
+        return fail(ctx, YH_ERR_STATE, "yh_scene_track_changes: TRS scenes recompute every row each frame");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_scene(s)) return rc;
+    if (enable && !s->chg) {
+        const uint64_t tile_words = ((uint64_t)s->n_tiles + 1) & ~1ull;
+        const uint64_t bytes = (32 + tile_words) * 4 + (uint64_t)s->n_chunks * 8;
+        HIP_TRY(ctx, hipMalloc((void**)&s->chg, bytes));
+        HIP_TRY(ctx, hipMemset(s->chg, 0, bytes));
+        s->chg_tilecnt = s->chg + 32;
+        s->chg_words = (uint64_t*)(s->chg_tilecnt + tile_words);
+        HIP_TRY(ctx, hipMalloc((void**)&s->chg_list, s->stride * 4));
+        HIP_TRY(ctx, hipHostMalloc((void**)&s->h_chg, 2 * YH_MAX_FRUSTA * 4, hipHostMallocMapped));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&s->h_chg_dev, s->h_chg, 0));
+        memset(s->h_chg, 0, 2 * YH_MAX_FRUSTA * 4);
+    }
+    s->track = enable != 0;
+    s->chg_valid = false;
+    return YH_OK;
+}
+
+extern "C" int yh_get_changed_count(yh_scene* s, uint64_t* n_changed) {
+    if (!s || !n_changed) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_get_changed_count: NULL argument");
+    if (!s->track || !s->chg_valid) return fail(s->ctx, YH_ERR_STATE, "yh_get_changed_count: no tracked frame has run");
+    if (s->frame_pending)
+        if (int rc = sync_scene(s)) return rc;
+    *n_changed = s->h_chg[0];
+    return YH_OK;
+}
+
+extern "C" int yh_download_changed_aos68(yh_scene* s, uint32_t* slots, void* world_rows, void* local_rows, uint64_t cap,
+                                         uint64_t* written) {
+    if (!s || !written) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_download_changed_aos68: NULL argument");
+    uint64_t n = 0;
+    if (int rc = yh_get_changed_count(s, &n)) return rc;
+    *written = n;
+    if (n > cap) return fail(s->ctx, YH_ERR_CAPACITY, "yh_download_changed_aos68: %llu rows changed, room for %llu",
+                             (unsigned long long)n, (unsigned long long)cap);
+    if (n == 0) return YH_OK;
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    if (slots) HIP_TRY(s->ctx, hipMemcpy(slots, s->chg_list, n * 4, hipMemcpyDeviceToHost));
+    // flags were cleared by the frame's sweep: rows come back with dirty = 0, as PostTransformSystem leaves them
+    if (world_rows)
+        if (int rc = download_aos68(s, world_rows, 0, n, s->world, s->wdirty, s->chg_list)) return rc;
+    if (local_rows)
+        if (int rc = download_aos68(s, local_rows, 0, n, s->lmat, s->ldirty, s->chg_list)) return rc;
+    return YH_OK;
 }
 
 extern "C" int yh_download_world_soa(yh_scene* s, float* const planes[16], uint64_t first, uint64_t count) {
@@ -803,10 +892,35 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
             ++launches;
         }
         // PostWorldTransform / PostLocalTransform (PostTransformSystem.zig:12-37)
-        hipLaunchKernelGGL(k_clear_dirty, dim3(cdiv(s->stride / 4, YH_BLOCK)), dim3(YH_BLOCK), 0, st, (uint32_t*)s->ldirty,
-                           (uint32_t*)s->wdirty, s->stride / 4);
-        HIP_TRY(ctx, hipGetLastError());
-        ++launches;
+        if (s->track) {
+            hipLaunchKernelGGL(k_sweep_dirty, dim3(cdiv(s->stride, YH_BLOCK)), dim3(YH_BLOCK), 0, st, s->ldirty, s->wdirty,
+                               (uint32_t)s->n, s->chg_words);
+            HIP_TRY(ctx, hipGetLastError());
+            ExpandArgs c;
+            memset(&c, 0, sizeof c);
+            c.vismask = s->chg_words;
+            c.tilecnt = s->chg_tilecnt;
+            c.counts = s->chg;
+            c.bcount_cur = s->chg + YH_MAX_FRUSTA;
+            c.bcount_next = s->chg + 2 * YH_MAX_FRUSTA;
+            c.host_counts = s->h_chg_dev;
+            c.draw[0] = s->chg_list;
+            c.draw_cap = s->stride;
+            c.n_chunks = s->n_chunks;
+            c.n_tiles = s->n_tiles;
+            c.words = s->tile_words;
+            c.self_count = s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES;
+            if (!c.self_count) hipLaunchKernelGGL(k_count, dim3(s->n_tiles, 1), dim3(YH_BLOCK), 0, st, c);
+            hipLaunchKernelGGL(k_expand, dim3(s->n_tiles, 1), dim3(YH_BLOCK), 0, st, c);
+            HIP_TRY(ctx, hipGetLastError());
+            s->chg_valid = true;
+            launches += c.self_count ? 2 : 3;
+        } else {
+            hipLaunchKernelGGL(k_clear_dirty, dim3(cdiv(s->stride / 4, YH_BLOCK)), dim3(YH_BLOCK), 0, st, (uint32_t*)s->ldirty,
+                               (uint32_t*)s->wdirty, s->stride / 4);
+            HIP_TRY(ctx, hipGetLastError());
+            ++launches;
+        }
     }
     s->root_dirty = 0;  // the world sweep clears the root's flag too
     if (cull) {

@@ -8,9 +8,13 @@
  *      slot order: a table's level is its parent's level + 1, tables whose parent is not itself matched (the scene
  *      root, GameApp.zig:77,95) are level 0; tables of one level are ordered by their parent's slot, which makes
  *      siblings contiguous and sorted by parent, as yh_upload_hierarchy wants (A10);
- *   3. copy both 68-byte columns of every table into slot order, yh_upload_*_aos68, yh_frame, yh_download_*_aos68,
- *      copy back.  The frame applies the three-branch rule (TransformSyncSystem.zig:53-74) level by level and then
- *      clears every dirty flag (PostTransformSystem.zig:27-37), the root's included.
+ *   3. plain mode: copy both 68-byte columns of every table into slot order, yh_upload_*_aos68, yh_frame,
+ *      yh_download_*_aos68, copy back.  Incremental mode (default): after a rebuild the same upload once; otherwise
+ *      only the rows whose OnSet fired since the last frame go up (yh_upload_*_rows_aos68: two observers collect them,
+ *      the same events that run the components' onSet hooks, the only writers of `dirty`), and only the rows the
+ *      frame recomputed or found dirty come back (yh_download_changed_aos68) — a frame in which nothing moved
+ *      exchanges no rows at all.  The frame applies the three-branch rule (TransformSyncSystem.zig:53-74) level by
+ *      level and then clears every dirty flag (PostTransformSystem.zig:27-37), the root's included.
  *
  * Difference from the CPU systems worth knowing: the reference visits tables in flecs' storage order and
  * is parent-first only when entities were created parent-first; a child table stored before its parent's table reads
@@ -79,6 +83,17 @@ struct GpuTransformCullSystem {
 
     float planes[YH_MAX_FRUSTA * 24];
     uint32_t n_frusta;
+
+    /* incremental mode: only rows whose onSet fired go up, only rows the frame touched come back */
+    int incremental;
+    Map slot_of;             /* entity -> slot, valid between rebuilds */
+    ecs_entity_t* dirty[2];  /* [0] LocalTransform, [1] WorldTransform: entities set since the last frame */
+    uint64_t n_dirty[2], cap_dirty[2];
+    uint32_t* stamp[2];      /* per slot: frame in which the row was last queued (duplicates in the dirty lists) */
+    uint32_t epoch;
+    uint32_t* slot_buf;      /* n entries: slots of a sparse upload / of the changed rows */
+    ecs_entity_t observers[2];
+    uint64_t last_up_rows, last_down_rows;
 
     int status;
     uint64_t rebuilds;
@@ -322,6 +337,26 @@ static int rebuild(GpuTransformCullSystem* s) {
                sizeof(ecs_entity_t) * s->batches[b].count);
     s->n_levels = n_levels;
     s->bounds_stale = 1;
+    /* entity -> slot, and the per-slot buffers of the incremental mode */
+    free(s->slot_of.e);
+    s->slot_of.e = NULL;
+    if (map_init(&s->slot_of, n) != 0) {
+        rc = YH_ERR_OOM;
+        goto done;
+    }
+    for (uint64_t e = 0; e < n; ++e) map_put(&s->slot_of, s->entity_of_slot[e], (uint32_t)e);
+    for (int k = 0; k < 2; ++k) {
+        free(s->stamp[k]);
+        s->stamp[k] = (uint32_t*)calloc((size_t)(n ? n : 1), sizeof(uint32_t));
+    }
+    free(s->slot_buf);
+    s->slot_buf = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n ? n : 1));
+    s->epoch = 0;
+    if (!s->stamp[0] || !s->stamp[1] || !s->slot_buf) {
+        rc = YH_ERR_OOM;
+        goto done;
+    }
+    if ((rc = yh_scene_track_changes(s->scene, s->incremental)) != YH_OK) goto done;
 
     /* remember this walk */
     {
@@ -389,6 +424,38 @@ static void restore_slots(GpuTransformCullSystem* s) {
     }
 }
 
+/* batch holding a slot: binary search over the batches in slot order */
+static const Batch* batch_of_slot(const GpuTransformCullSystem* s, uint32_t slot) {
+    uint32_t lo = 0, hi = s->n_batches - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) / 2;
+        if (s->batches[s->order[mid]].slot_begin <= slot) lo = mid;
+        else hi = mid - 1;
+    }
+    return &s->batches[s->order[lo]];
+}
+
+/* OnSet observers: the same events that run the components' onSet hooks */
+static void note_set(ecs_iter_t* it, int k) {
+    GpuTransformCullSystem* s = (GpuTransformCullSystem*)it->ctx;
+    if (!s->incremental) return;
+    if (s->n_dirty[k] + (uint64_t)it->count > s->cap_dirty[k]) {
+        uint64_t cap = s->cap_dirty[k] ? s->cap_dirty[k] * 2 : 1024;
+        while (cap < s->n_dirty[k] + (uint64_t)it->count) cap *= 2;
+        ecs_entity_t* d = (ecs_entity_t*)realloc(s->dirty[k], cap * sizeof(ecs_entity_t));
+        if (!d) {
+            s->cached_n = 0; /* out of memory: force a rebuild, i.e. a full upload, next frame */
+            return;
+        }
+        s->dirty[k] = d;
+        s->cap_dirty[k] = cap;
+    }
+    memcpy(s->dirty[k] + s->n_dirty[k], it->entities, sizeof(ecs_entity_t) * (size_t)it->count);
+    s->n_dirty[k] += (uint64_t)it->count;
+}
+static void on_set_local(ecs_iter_t* it) { note_set(it, 0); }
+static void on_set_world(ecs_iter_t* it) { note_set(it, 1); }
+
 static void run(ecs_iter_t* it) {
     GpuTransformCullSystem* s = (GpuTransformCullSystem*)it->ctx;
     int rc = walk(s, it);
@@ -396,7 +463,8 @@ static void run(ecs_iter_t* it) {
         s->status = rc;
         return;
     }
-    if (same_as_last_walk(s)) restore_slots(s);
+    const int rebuilt = !same_as_last_walk(s);
+    if (!rebuilt) restore_slots(s);
     else if ((rc = rebuild(s)) != YH_OK) {
         s->status = rc;
         return;
@@ -424,23 +492,78 @@ static void run(ecs_iter_t* it) {
         s->status = rc;
         return;
     }
-    for (uint32_t i = 0; i < s->n_batches; ++i) {
-        const Batch* b = &s->batches[i];
-        memcpy(s->stage_w + (size_t)b->slot_begin * ROW, b->world_col, (size_t)b->count * ROW);
-        memcpy(s->stage_l + (size_t)b->slot_begin * ROW, b->local_col, (size_t)b->count * ROW);
+    const uint32_t cull_flags = s->n_frusta ? 0u : YH_FRAME_NO_CULL;
+    if (!s->incremental || rebuilt) {
+        /* whole columns up; in plain mode whole columns down again */
+        for (uint32_t i = 0; i < s->n_batches; ++i) {
+            const Batch* b = &s->batches[i];
+            memcpy(s->stage_w + (size_t)b->slot_begin * ROW, b->world_col, (size_t)b->count * ROW);
+            memcpy(s->stage_l + (size_t)b->slot_begin * ROW, b->local_col, (size_t)b->count * ROW);
+        }
+        if ((rc = yh_upload_world_aos68(s->scene, s->stage_w, 0, s->n)) != YH_OK ||
+            (rc = yh_upload_local_aos68(s->scene, s->stage_l, 0, s->n)) != YH_OK) {
+            s->status = rc;
+            return;
+        }
+        s->last_up_rows = 2 * s->n;
+    } else {
+        /* the rows whose onSet hook fired since the last frame (transform.zig:46-51, 92-97: the only writers of dirty) */
+        s->epoch += 1;
+        s->last_up_rows = 0;
+        for (int k = 0; k < 2; ++k) {
+            uint8_t* stage = k == 0 ? s->stage_l : s->stage_w;
+            uint64_t m = 0;
+            for (uint64_t i = 0; i < s->n_dirty[k]; ++i) {
+                uint32_t slot;
+                if (!map_get(&s->slot_of, s->dirty[k][i], &slot) || s->stamp[k][slot] == s->epoch) continue;
+                s->stamp[k][slot] = s->epoch;
+                const Batch* b = batch_of_slot(s, slot);
+                const uint8_t* col = (const uint8_t*)(k == 0 ? b->local_col : b->world_col);
+                memcpy(stage + m * ROW, col + (size_t)(slot - b->slot_begin) * ROW, ROW);
+                s->slot_buf[m++] = slot;
+            }
+            rc = k == 0 ? yh_upload_local_rows_aos68(s->scene, s->slot_buf, stage, m)
+                        : yh_upload_world_rows_aos68(s->scene, s->slot_buf, stage, m);
+            if (rc != YH_OK) {
+                s->status = rc;
+                return;
+            }
+            s->last_up_rows += m;
+        }
     }
-    if ((rc = yh_upload_world_aos68(s->scene, s->stage_w, 0, s->n)) != YH_OK ||
-        (rc = yh_upload_local_aos68(s->scene, s->stage_l, 0, s->n)) != YH_OK ||
-        (rc = yh_frame(s->scene, s->planes, s->n_frusta, s->n_frusta ? 0u : YH_FRAME_NO_CULL)) != YH_OK ||
-        (rc = yh_download_world_aos68(s->scene, s->stage_w, 0, s->n)) != YH_OK ||
-        (rc = yh_download_local_aos68(s->scene, s->stage_l, 0, s->n)) != YH_OK) {
+    s->n_dirty[0] = s->n_dirty[1] = 0;
+    if ((rc = yh_frame(s->scene, s->planes, s->n_frusta, cull_flags)) != YH_OK) {
         s->status = rc;
         return;
     }
-    for (uint32_t i = 0; i < s->n_batches; ++i) {
-        const Batch* b = &s->batches[i];
-        memcpy(b->world_col, s->stage_w + (size_t)b->slot_begin * ROW, (size_t)b->count * ROW);
-        memcpy(b->local_col, s->stage_l + (size_t)b->slot_begin * ROW, (size_t)b->count * ROW);
+    if (!s->incremental) {
+        if ((rc = yh_download_world_aos68(s->scene, s->stage_w, 0, s->n)) != YH_OK ||
+            (rc = yh_download_local_aos68(s->scene, s->stage_l, 0, s->n)) != YH_OK) {
+            s->status = rc;
+            return;
+        }
+        for (uint32_t i = 0; i < s->n_batches; ++i) {
+            const Batch* b = &s->batches[i];
+            memcpy(b->world_col, s->stage_w + (size_t)b->slot_begin * ROW, (size_t)b->count * ROW);
+            memcpy(b->local_col, s->stage_l + (size_t)b->slot_begin * ROW, (size_t)b->count * ROW);
+        }
+        s->last_down_rows = 2 * s->n;
+    } else {
+        /* every row the frame recomputed or found dirty, flags cleared; all other rows are as flecs holds them */
+        uint64_t m = 0;
+        if ((rc = yh_download_changed_aos68(s->scene, s->slot_buf, s->stage_w, s->stage_l, s->n, &m)) != YH_OK) {
+            s->status = rc;
+            return;
+        }
+        const Batch* b = NULL;
+        for (uint64_t i = 0; i < m; ++i) { /* ascending slots: the batch changes rarely */
+            const uint32_t slot = s->slot_buf[i];
+            if (!b || slot < b->slot_begin || slot >= b->slot_begin + b->count) b = batch_of_slot(s, slot);
+            const size_t r = (size_t)(slot - b->slot_begin) * ROW;
+            memcpy((uint8_t*)b->world_col + r, s->stage_w + i * ROW, ROW);
+            memcpy((uint8_t*)b->local_col + r, s->stage_l + i * ROW, ROW);
+        }
+        s->last_down_rows = 2 * m;
     }
     if (root_row) root_row[64] = 0; /* PostWorldTransform reaches the root too (single-term query) */
     s->status = YH_OK;
@@ -479,6 +602,16 @@ ecs_entity_t GpuTransformCullSystem_registerTo(ecs_world_t* world, ecs_entity_t 
     if (!s->system) {
         free(s);
         return 0;
+    }
+    s->incremental = 1;
+    for (int k = 0; k < 2; ++k) {
+        ecs_observer_desc_t od;
+        memset(&od, 0, sizeof od);
+        od.query.terms[0].id = k == 0 ? local_transform : world_transform;
+        od.events[0] = EcsOnSet;
+        od.callback = k == 0 ? on_set_local : on_set_world;
+        od.ctx = s;
+        s->observers[k] = ecs_observer_init(world, &od);
     }
     *out_state = s;
     return s->system;
@@ -534,6 +667,19 @@ uint64_t GpuTransformCullSystem_entities(const GpuTransformCullSystem* s) { retu
 uint32_t GpuTransformCullSystem_levels(const GpuTransformCullSystem* s) { return s ? s->n_levels : 0; }
 uint64_t GpuTransformCullSystem_rebuilds(const GpuTransformCullSystem* s) { return s ? s->rebuilds : 0; }
 
+int GpuTransformCullSystem_setIncremental(GpuTransformCullSystem* s, int on) {
+    if (!s) return YH_ERR_BAD_ARG;
+    s->incremental = on != 0;
+    s->cached_n = 0; /* the next frame rebuilds: whole columns travel once, tracking is switched on the scene */
+    s->n_dirty[0] = s->n_dirty[1] = 0;
+    return YH_OK;
+}
+
+void GpuTransformCullSystem_lastTraffic(const GpuTransformCullSystem* s, uint64_t* rows_up, uint64_t* rows_down) {
+    if (rows_up) *rows_up = s ? s->last_up_rows : 0;
+    if (rows_down) *rows_down = s ? s->last_down_rows : 0;
+}
+
 void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     if (!s) return;
     if (s->scene) yh_scene_destroy(s->scene);
@@ -548,5 +694,12 @@ void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     free(s->stage_w);
     free(s->stage_l);
     free(s->bounds);
+    free(s->slot_of.e);
+    for (int k = 0; k < 2; ++k) {
+        free(s->dirty[k]);
+        free(s->stamp[k]);
+        if (s->observers[k] && s->world) ecs_delete(s->world, s->observers[k]);
+    }
+    free(s->slot_buf);
     free(s);
 }

@@ -51,6 +51,12 @@ uint64_t GpuTransformCullSystem_entities(const GpuTransformCullSystem* s);
 uint32_t GpuTransformCullSystem_levels(const GpuTransformCullSystem* s);
 uint64_t GpuTransformCullSystem_rebuilds(const GpuTransformCullSystem* s);
 
+/* Incremental mode (on by default): only rows whose onSet fired are uploaded, only rows the frame touched are
+ * downloaded.  Off: whole columns both ways every frame.  Switching costs one full upload. */
+int GpuTransformCullSystem_setIncremental(GpuTransformCullSystem* s, int on);
+/* 68-byte rows that crossed PCIe in the last frame, each direction (both components counted). */
+void GpuTransformCullSystem_lastTraffic(const GpuTransformCullSystem* s, uint64_t* rows_up, uint64_t* rows_down);
+
 void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s);
 
 #ifdef __cplusplus

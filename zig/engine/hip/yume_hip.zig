@@ -53,6 +53,11 @@ pub extern fn yh_set_root(s: *Scene, root_world: *const [16]f32) c_int;
 pub extern fn yh_upload_root_aos68(s: *Scene, row: *const anyopaque) c_int;
 pub extern fn yh_upload_local_aos68(s: *Scene, column: *const anyopaque, first: u64, count: u64) c_int;
 pub extern fn yh_upload_world_aos68(s: *Scene, column: *const anyopaque, first: u64, count: u64) c_int;
+pub extern fn yh_upload_local_rows_aos68(s: *Scene, slots: [*]const u32, rows: *const anyopaque, count: u64) c_int;
+pub extern fn yh_upload_world_rows_aos68(s: *Scene, slots: [*]const u32, rows: *const anyopaque, count: u64) c_int;
+pub extern fn yh_scene_track_changes(s: *Scene, enable: c_int) c_int;
+pub extern fn yh_get_changed_count(s: *Scene, n_changed: *u64) c_int;
+pub extern fn yh_download_changed_aos68(s: *Scene, slots: ?[*]u32, world_rows: ?*anyopaque, local_rows: ?*anyopaque, cap: u64, written: *u64) c_int;
 pub extern fn yh_mark_dirty(s: *Scene, local: c_int, world: c_int, first: u64, count: u64) c_int;
 pub extern fn yh_upload_aabb(s: *Scene, min_planes: *const [3][*]const f32, max_planes: *const [3][*]const f32, first: u64, count: u64) c_int;
 pub extern fn yh_frame(s: *Scene, planes: ?[*]const f32, n_frusta: u32, flags: u32) c_int;

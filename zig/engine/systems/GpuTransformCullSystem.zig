@@ -26,6 +26,8 @@ extern fn GpuTransformCullSystem_registerTo(
 extern fn GpuTransformCullSystem_setBounds(s: *State, entity: c.ecs_entity_t, min_max: *const [6]f32) c_int;
 extern fn GpuTransformCullSystem_setFrusta(s: *State, planes: [*]const f32, n_frusta: u32) c_int;
 extern fn GpuTransformCullSystem_visible(s: *State, frustum: u32, out: ?[*]c.ecs_entity_t, cap: u64) u64;
+extern fn GpuTransformCullSystem_setIncremental(s: *State, on: c_int) c_int;
+extern fn GpuTransformCullSystem_lastTraffic(s: *const State, rows_up: ?*u64, rows_down: ?*u64) void;
 extern fn GpuTransformCullSystem_status(s: *const State) c_int;
 extern fn GpuTransformCullSystem_destroy(s: ?*State) void;
 
