@@ -172,6 +172,23 @@ int yh_scene_track_changes(yh_scene* s, int enable);
 int yh_get_changed_count(yh_scene* s, uint64_t* n_changed);
 int yh_download_changed_aos68(yh_scene* s, uint32_t* slots, void* world_rows, void* local_rows, uint64_t cap,
                               uint64_t* written);
+/* ---- draw-list consumer ------------------------------------------------------------------------
+ * What the reference's draw loop does on the CPU for every object it is handed, here on the device for the visible
+ * entities of one frustum, in list order i = 0 .. count-1:
+ *   object_data[i] = GPUObjectData{ model_matrix = WorldTransform.matrix }   (GAL/vulkan/RenderApi.zig:97-99, 1397-1404)
+ *   cmd[i] = { vertices_count, 1, 0, batch_offset + i }                      (vkCmdDraw arguments, :1441)
+ * yh_upload_vertex_counts: mesh.vertices_count per mesh (mesh-table scenes, n <= max_meshes) or per entity
+ * (n = n_entities); without it vertex_count is 0.  yh_build_object_data enqueues after yh_frame (no host sync);
+ * yh_get_object_data copies to the host; yh_object_data_device hands out the device buffers for an importing
+ * renderer (valid until the scene is destroyed; contents until the next build).                            */
+typedef struct yh_draw_cmd {
+    uint32_t vertex_count, instance_count, first_vertex, first_instance; /* VkDrawIndirectCommand */
+} yh_draw_cmd;
+int yh_upload_vertex_counts(yh_scene* s, const uint32_t* counts, uint64_t n);
+int yh_build_object_data(yh_scene* s, uint32_t frustum, uint32_t batch_offset);
+int yh_get_object_data(yh_scene* s, uint32_t frustum, void* model_matrices, yh_draw_cmd* cmds, uint64_t cap,
+                       uint64_t* written);
+void* yh_object_data_device(yh_scene* s, uint32_t frustum, void** cmds_device);
 /* Stage 1 alone: Mat4.compose over a range, result as 16 SoA planes on the host (testing aid).          */
 int yh_compose(yh_scene* s, float* const planes[16], uint64_t first, uint64_t count);
 

@@ -269,6 +269,52 @@ def test_mesh_table_bounds(ctx, oracle):
         assert np.array_equal(s.draw_list(0), np.flatnonzero(vis[0]).astype(np.uint32) + np.uint32(base))
 
 
+def test_draw_list_consumer_object_data_and_draw_records(ctx, oracle):
+    """GPUObjectData{model_matrix} and vkCmdDraw arguments for the visible entities, in list order —
+    the reference fills them on the CPU (GAL/vulkan/RenderApi.zig:1397-1404, 1441)."""
+    from yume_amd import Scene, _lib
+
+    # hierarchy, per-entity bounds, per-entity vertex counts, two frusta
+    lo, par, trs, bounds = make_scene(oracle, 300_000, 6)
+    n = trs.shape[1]
+    planes = np.concatenate([oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()[:1]])
+    vcount = (np.arange(n, dtype=np.uint32) * 7 + 3) % 1000
+    with gpu_scene(ctx, lo, par, trs, bounds, 2) as s:
+        with pytest.raises(_lib.YumeHipError) as e:
+            s.object_data(0)
+        assert e.value.code == _lib.YH_ERR_STATE  # no frame yet
+        s.upload_vertex_counts(vcount)
+        s.frame(planes)
+        exp = oracle.frame_trs(trs, par, lo)
+        for f, off in ((0, 0), (1, 5000)):
+            lst = s.draw_list(f)
+            m, c = s.object_data(f, batch_offset=off)
+            assert m.shape[0] == lst.size > 0
+            assert_same_values(m, exp["m"][lst], f"object data {f}")
+            assert np.array_equal(c[:, 0], vcount[lst]) and np.all(c[:, 1] == 1) and np.all(c[:, 2] == 0)
+            assert np.array_equal(c[:, 3], off + np.arange(lst.size, dtype=np.uint32))
+        with pytest.raises(_lib.YumeHipError):
+            s.upload_vertex_counts(vcount[:10])  # per-entity scenes want n counts
+
+    # instanced: mesh table, vertex count per mesh, global ids offset by id_base
+    n, nm, base = 200_000, 16, 4096
+    trs = oracle.synth_trs(n, n)
+    ids = oracle.synth_mesh_ids(n, nm)
+    per_mesh = np.arange(nm, dtype=np.uint32) * 36 + 12
+    with Scene(ctx, n, n_frusta=1, bounds_kind=2, max_meshes=nm, id_base=base) as s:
+        s.upload_flat()
+        s.upload_trs(trs)
+        s.upload_mesh_aabbs(oracle.synth_mesh_table(nm))
+        s.upload_mesh_ids(ids)
+        s.upload_vertex_counts(per_mesh)
+        s.frame(planes[:1])
+        lst = s.draw_list(0) - np.uint32(base)
+        m, c = s.object_data(0)
+        exp = oracle.frame_trs(trs, np.full(n, 0xFFFFFFFF, np.uint32), np.array([0, n], np.uint32))
+        assert_same_values(m, exp["m"][lst], "instanced object data")
+        assert np.array_equal(c[:, 0], per_mesh[ids[lst]])
+
+
 def test_boundary_cases_are_counted(ctx, oracle):
     """Entities placed exactly on / within 1e-5 of a plane are reported in boundary_counts."""
     from yume_amd import Scene

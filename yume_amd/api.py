@@ -217,6 +217,23 @@ class Scene:
         self._ck(L.lib().yh_download_local_aos68(self._h, _ptr(out), first, count))
         return out
 
+    # ---- draw-list consumer ----
+    def upload_vertex_counts(self, counts):
+        counts = np.ascontiguousarray(counts, np.uint32)
+        self._ck(L.lib().yh_upload_vertex_counts(self._h, _ptr(counts), counts.size))
+
+    def object_data(self, frustum=0, batch_offset=0):
+        """(model matrices [k,16], draw records [k,4]) of the frustum's visible entities, list order."""
+        self._ck(L.lib().yh_build_object_data(self._h, frustum, batch_offset))
+        counts, _ = self.counts()
+        k = int(counts[frustum])
+        m = np.zeros((k, 16), np.float32)
+        c = np.zeros((k, 4), np.uint32)
+        wr = C.c_uint64()
+        self._ck(L.lib().yh_get_object_data(self._h, frustum, _ptr(m), _ptr(c), k, C.byref(wr)))
+        assert wr.value == k
+        return m, c
+
     # ---- sparse rows / change tracking (Mat4 scenes) ----
     def upload_local_rows(self, slots, rows):
         slots = np.ascontiguousarray(slots, np.uint32)

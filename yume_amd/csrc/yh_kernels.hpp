@@ -531,6 +531,36 @@ __global__ __launch_bounds__(YH_BLOCK) void k_soa_to_aos68(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Draw-list consumer: what the reference's draw loop does on the CPU for every object it is handed
+// (GAL/vulkan/RenderApi.zig:1397-1404: object_data_arr[batch_offset + index] = GPUObjectData{model_matrix};
+// :1441 vkCmdDraw(vertices_count, 1, 0, batch_offset + index)), here for the visible entities of one frustum in list
+// order: 64-byte model matrices (transposed through LDS so the stores are coalesced) and one
+// VkDrawIndirectCommand-shaped record each.  The list length is read on the device: no host sync before the launch.
+__global__ __launch_bounds__(YH_BLOCK) void k_build_objects(const float* __restrict__ world, const uint32_t* __restrict__ list,
+                                                            const uint32_t* __restrict__ count_ptr, uint64_t cap,
+                                                            uint32_t id_base, const uint32_t* __restrict__ vcount,
+                                                            const uint32_t* __restrict__ mesh_id, uint32_t batch_offset,
+                                                            uint32_t* __restrict__ obj, uint4* __restrict__ cmds) {
+    __shared__ uint32_t tile[YH_BLOCK * 17];
+    uint64_t count = *count_ptr;
+    if (count > cap) count = cap;
+    const uint64_t r0 = (uint64_t)blockIdx.x * YH_BLOCK;
+    if (r0 >= count) return;
+    const uint64_t nrows = (count - r0 < YH_BLOCK) ? (count - r0) : YH_BLOCK;
+    if (threadIdx.x < nrows) {
+        const uint32_t e = list[r0 + threadIdx.x] - id_base;
+        const uint64_t off = eoff<16>(e);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tile[threadIdx.x * 17 + q] = __float_as_uint(lde(world, off, q));
+        const uint32_t vc = vcount ? vcount[mesh_id ? mesh_id[e] : e] : 0u;
+        cmds[r0 + threadIdx.x] = make_uint4(vc, 1u, 0u, batch_offset + (uint32_t)(r0 + threadIdx.x));
+    }
+    __syncthreads();
+    const uint32_t ndw = (uint32_t)nrows * 16u;
+    for (uint32_t i = threadIdx.x; i < ndw; i += YH_BLOCK) obj[r0 * 16 + i] = tile[(i >> 4) * 17 + (i & 15u)];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Synthetic scene generator: TRS + bounds from the counter-based hash, bit-identical to
 // the oracle's host generator.  Level 0 (local index < n_level0) draws from the wide ranges.
 __global__ __launch_bounds__(YH_BLOCK) void k_synth(float* __restrict__ trs, float* __restrict__ bounds,

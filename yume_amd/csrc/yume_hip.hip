@@ -70,6 +70,10 @@ struct yh_scene {
     uint32_t* h_chg = nullptr;        // host-mapped totals written by k_expand
     uint32_t* h_chg_dev = nullptr;
     bool chg_valid = false;           // a tracked frame has run since tracking was enabled
+    // draw-list consumer (N2): per frustum, model matrices + draw records of the visible entities, list order
+    uint32_t* obj[YH_MAX_FRUSTA] = {};
+    uint4* cmd[YH_MAX_FRUSTA] = {};
+    uint32_t* vcount = nullptr;       // vertices per mesh (mesh-table scenes) or per entity
     void* staging = nullptr;          // device staging for AoS68 import/export
     uint64_t staging_bytes = 0;
     std::vector<uint32_t> level_offsets;
@@ -205,7 +209,10 @@ static void scene_free(yh_scene* s) {
                     s->staging, s->d_all_counts, s->chg, s->chg_list};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->vcount) (void)hipFree(s->vcount);
     for (uint32_t f = 0; f < YH_MAX_FRUSTA; ++f) {
+        if (s->obj[f]) (void)hipFree(s->obj[f]);
+        if (s->cmd[f]) (void)hipFree(s->cmd[f]);
         if (s->draw[f]) (void)hipFree(s->draw[f]);
         if (s->gathered[f]) (void)hipFree(s->gathered[f]);
     }
@@ -990,6 +997,64 @@ extern "C" int yh_get_draw_list(yh_scene* s, uint32_t frustum, uint32_t* out, ui
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     if (c) HIP_TRY(s->ctx, hipMemcpy(out, s->draw[frustum], c * 4, hipMemcpyDeviceToHost));
     return YH_OK;
+}
+
+// ---- draw-list consumer -----------------------------------------------------------------------
+extern "C" int yh_upload_vertex_counts(yh_scene* s, const uint32_t* counts, uint64_t n) {
+    if (!s || !counts) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_upload_vertex_counts: NULL argument");
+    yh_ctx* ctx = s->ctx;
+    const bool table = s->desc.bounds_kind == YH_BOUNDS_MESH_TABLE;
+    const uint64_t want = table ? s->desc.max_meshes : s->n;
+    if (table ? (n == 0 || n > want) : (n != want))
+        return fail(ctx, YH_ERR_BAD_ARG, "yh_upload_vertex_counts: %llu counts, scene wants %s%llu", (unsigned long long)n,
+                    table ? "at most " : "", (unsigned long long)want);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_scene(s)) return rc;
+    if (!s->vcount) {
+        HIP_TRY(ctx, hipMalloc((void**)&s->vcount, want * 4));
+        HIP_TRY(ctx, hipMemset(s->vcount, 0, want * 4));
+    }
+    HIP_TRY(ctx, hipMemcpy(s->vcount, counts, n * 4, hipMemcpyHostToDevice));
+    return YH_OK;
+}
+
+extern "C" int yh_build_object_data(yh_scene* s, uint32_t frustum, uint32_t batch_offset) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_build_object_data: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    if (frustum >= s->last_n_frusta) return fail(ctx, YH_ERR_STATE, "yh_build_object_data: frustum %u was not culled by the last frame", frustum);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!s->obj[frustum]) {
+        HIP_TRY(ctx, hipMalloc((void**)&s->obj[frustum], s->draw_cap * 64));
+        HIP_TRY(ctx, hipMalloc((void**)&s->cmd[frustum], s->draw_cap * 16));
+    }
+    hipLaunchKernelGGL(k_build_objects, dim3(cdiv(std::min<uint64_t>(s->n, s->draw_cap), YH_BLOCK)), dim3(YH_BLOCK), 0, ctx->stream,
+                       s->world, s->draw[frustum], s->counts + frustum, s->draw_cap, s->desc.id_base, s->vcount,
+                       s->desc.bounds_kind == YH_BOUNDS_MESH_TABLE ? s->mesh_id : nullptr, batch_offset, s->obj[frustum],
+                       s->cmd[frustum]);
+    HIP_TRY(ctx, hipGetLastError());
+    s->frame_pending = true;
+    return YH_OK;
+}
+
+extern "C" int yh_get_object_data(yh_scene* s, uint32_t frustum, void* model_matrices, yh_draw_cmd* cmds, uint64_t cap,
+                                  uint64_t* written) {
+    if (!s || !written) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_get_object_data: NULL argument");
+    yh_ctx* ctx = s->ctx;
+    if (frustum >= YH_MAX_FRUSTA || !s->obj[frustum]) return fail(ctx, YH_ERR_STATE, "yh_get_object_data: call yh_build_object_data first");
+    if (int rc = sync_scene(s)) return rc;
+    const uint64_t n = std::min<uint64_t>(s->h_counts[frustum], s->draw_cap);
+    *written = n;
+    if (n > cap) return fail(ctx, YH_ERR_CAPACITY, "yh_get_object_data: %llu objects, room for %llu", (unsigned long long)n, (unsigned long long)cap);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (model_matrices && n) HIP_TRY(ctx, hipMemcpy(model_matrices, s->obj[frustum], n * 64, hipMemcpyDeviceToHost));
+    if (cmds && n) HIP_TRY(ctx, hipMemcpy(cmds, s->cmd[frustum], n * 16, hipMemcpyDeviceToHost));
+    return YH_OK;
+}
+
+extern "C" void* yh_object_data_device(yh_scene* s, uint32_t frustum, void** cmds_device) {
+    if (!s || frustum >= YH_MAX_FRUSTA) return nullptr;
+    if (cmds_device) *cmds_device = s->cmd[frustum];
+    return s->obj[frustum];
 }
 
 extern "C" int yh_timings(yh_scene* s, yh_timing* out) {
