@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--entities", type=int, default=0, help="override entities per GPU")
     ap.add_argument("--grouping", type=int, default=0, help="levels per launch (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="rehearsal on one GPU: bring up a one-rank RCCL communicator and run the multi-GPU step "
+                         "(frame + pipelined all-gather) - measures what the exchange adds to a frame")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -201,6 +204,10 @@ def main():
 
     collective = "none"
     use_lib_comm = True
+    gather = world_size > 1 or args.force_comm
+    if world_size == 1 and args.force_comm:
+        ctx.comm_init(1, 0, Context.comm_unique_id())
+        collective = "rccl (library, collective stream), one-rank rehearsal"
     if world_size > 1:
         # product path: the library's own RCCL communicator (ncclAllGather of counts + grouped ncclBroadcast of the
         # exact-size lists on the library's stream).  If it cannot be brought up on every rank, stand by with
@@ -211,21 +218,24 @@ def main():
             dist.broadcast_object_list(ids, src=0)
             ctx.comm_init(world_size, rank, ids[0])
             scene.frame(planes, _lib.YH_FRAME_ALL_DIRTY)
-            scene.allgather_draw_lists()
+            scene.allgather_draw_lists()        # exact-size exchange (host sync): checks the communicator end to end
+            scene.allgather_draw_lists_async()  # the pipelined exchange the timed frames use
+            scene.gathered_counts(F)
             ok = 1
         except Exception as ex:  # noqa: BLE001
             ok, err = 0, str(ex)
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         use_lib_comm = bool(flag.item())
-        collective = ("rccl (library): allgather(counts) + grouped bcast(exact-size lists)" if use_lib_comm
+        collective = ("rccl (library, collective stream): allgather(counts) + allgather(lists padded to capacity) + pack, "
+                      "overlapping the next frame's transforms" if use_lib_comm
                       else f"torch.distributed nccl stand-by (library communicator failed: {err[:120]})")
 
     def step():
         scene.frame(planes, flags)
-        if world_size > 1:
+        if gather:
             if use_lib_comm:
-                scene.allgather_draw_lists()
+                scene.allgather_draw_lists_async()
             else:
                 from yume_amd import shard
 
@@ -310,7 +320,7 @@ def main():
     for _ in range(min(50, args.steps)):
         a = time.perf_counter()
         scene.frame(planes, _lib.YH_FRAME_ALL_DIRTY)
-        if world_size > 1 and use_lib_comm:
+        if gather and use_lib_comm:
             scene.allgather_draw_lists()
         lat.append(time.perf_counter() - a)
 

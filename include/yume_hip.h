@@ -254,6 +254,11 @@ void yh_comm_destroy(yh_ctx* ctx);
 /* All-gather of per-rank visible counts, then of the compacted draw lists (exact sizes, written at
  * prefix-sum offsets into a library-owned gathered list per frustum).  all_counts: n_ranks x n_frusta.   */
 int yh_allgather_draw_lists(yh_scene* s, uint32_t* all_counts /* may be NULL */);
+/* The same exchange without a host round trip: everything is enqueued on the context's collective stream behind
+ * this frame and overlaps the next frame's transform launches; lists travel padded to draw_capacity.  Counts and
+ * lists are read afterwards with yh_get_gathered_counts / yh_get_gathered_draw_list (they synchronise).     */
+int yh_allgather_draw_lists_async(yh_scene* s);
+int yh_get_gathered_counts(yh_scene* s, uint32_t* all_counts /* n_ranks x n_frusta */);
 int yh_get_gathered_draw_list(yh_scene* s, uint32_t frustum, uint32_t* out, uint64_t cap, uint64_t* written);
 
 #ifdef __cplusplus

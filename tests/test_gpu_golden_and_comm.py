@@ -55,6 +55,37 @@ def test_rccl_one_rank_allgather(oracle):
             assert np.array_equal(s.allgather_draw_lists()[0], counts[:2])
 
 
+def test_rccl_one_rank_allgather_without_host_sync(oracle):
+    """The pipelined exchange (collective stream, padded all-gather + packing kernel): same lists, frame after frame."""
+    from yume_amd import Context, Scene, _lib
+
+    n = 300_000
+    lo = oracle.synth_level_offsets(n, 6)
+    par = oracle.synth_parents(lo)
+    cams = [oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()[:1], oracle.cascade_planes()[1:2]]
+    with Context(0) as c:
+        c.comm_init(1, 0, Context.comm_unique_id())
+        with Scene(c, n, n_levels=6, n_frusta=2, id_base=11) as s:
+            s.upload_hierarchy(par, lo)
+            s.fill_synthetic()
+            flags = _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC
+            for k in range(4):  # back-to-back frames with different second frusta: each gather must see its own frame
+                planes = np.concatenate([cams[0], cams[1 + k % 2]])
+                s.frame(planes, flags)
+                s.allgather_draw_lists_async()
+                if k % 2 == 1:
+                    s.frame(planes, flags)  # a frame enqueued behind a pending gather: its expansion has to wait
+                    s.allgather_draw_lists_async()
+                counts, _ = s.counts()
+                gc = s.gathered_counts(2)
+                assert gc.shape == (1, 2) and np.array_equal(gc[0], counts[:2])
+                for f in range(2):
+                    assert np.array_equal(s.gathered_draw_list(f, gc[0, f]), s.draw_list(f))
+            # the synchronous exchange still works afterwards
+            assert np.array_equal(s.allgather_draw_lists()[0], counts[:2])
+            assert np.array_equal(s.gathered_draw_list(1, counts[1]), s.draw_list(1))
+
+
 def test_allgather_without_communicator_is_a_state_error(ctx, oracle):
     from yume_amd import Scene, _lib
 

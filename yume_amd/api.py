@@ -310,6 +310,15 @@ class Scene:
         self._ck(L.lib().yh_allgather_draw_lists(self._h, _ptr(out)))
         return out
 
+    def allgather_draw_lists_async(self):
+        """Enqueue the exchange (no host sync); read with gathered_counts() / gathered_draw_list()."""
+        self._ck(L.lib().yh_allgather_draw_lists_async(self._h))
+
+    def gathered_counts(self, n_frusta):
+        out = np.zeros((self.ctx.n_ranks, max(1, n_frusta)), np.uint32)
+        self._ck(L.lib().yh_get_gathered_counts(self._h, _ptr(out)))
+        return out
+
     def gathered_draw_list(self, frustum, total):
         out = np.empty(int(total), np.uint32)
         written = C.c_uint64()

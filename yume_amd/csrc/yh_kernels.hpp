@@ -530,6 +530,25 @@ __global__ __launch_bounds__(YH_BLOCK) void k_soa_to_aos68(const float* __restri
     for (uint32_t i = threadIdx.x; i < ndw; i += YH_BLOCK) rows[r0 * 17 + i] = tile[i];
 }
 
+// Multi-GPU, no-host-sync gather: every rank's list arrives padded to the list capacity ([rank][cap]); the counts
+// arrive by their own all-gather.  One pass packs the R lists back to back (rank order = ascending global ids when
+// shards own ascending id ranges).  grid = (cap / 256, R).
+__global__ __launch_bounds__(YH_BLOCK) void k_compact_gathered(const uint32_t* __restrict__ padded,
+                                                               const uint32_t* __restrict__ all_counts, uint32_t frustum,
+                                                               uint64_t cap, uint32_t* __restrict__ out) {
+    const uint32_t r = blockIdx.y;
+    uint64_t count = all_counts[r * YH_K_MAX_FRUSTA + frustum];
+    if (count > cap) count = cap;
+    const uint64_t i = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;
+    if (i >= count) return;
+    uint64_t off = 0;
+    for (uint32_t q = 0; q < r; ++q) {
+        const uint64_t c = all_counts[q * YH_K_MAX_FRUSTA + frustum];
+        off += c < cap ? c : cap;
+    }
+    out[off + i] = padded[(uint64_t)r * cap + i];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Draw-list consumer: what the reference's draw loop does on the CPU for every object it is handed
 // (GAL/vulkan/RenderApi.zig:1397-1404: object_data_arr[batch_offset + index] = GPUObjectData{model_matrix};

@@ -26,6 +26,7 @@ static_assert(YH_MAX_FRUSTA == YH_K_MAX_FRUSTA, "header / kernel frustum limits 
 struct yh_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream_c = nullptr;  // collectives of the no-host-sync gather (created by yh_comm_init)
     hipDeviceProp_t prop{};
     std::string err;
     // RCCL (optional)
@@ -103,6 +104,11 @@ struct yh_scene {
     uint32_t* gathered[YH_MAX_FRUSTA] = {};
     uint64_t gathered_cap[YH_MAX_FRUSTA] = {};
     uint64_t gathered_len[YH_MAX_FRUSTA] = {};
+    // no-host-sync gather (yh_allgather_draw_lists_async)
+    uint32_t* padded[YH_MAX_FRUSTA] = {};  // [rank][draw_cap] receive buffers
+    hipEvent_t ev_frame = nullptr, ev_comm = nullptr;
+    bool comm_pending = false;    // the next expansion must wait for ev_comm: the gather still reads the lists
+    bool gathered_async = false;  // gathered_len is to be derived from h_all_counts after a sync
 };
 
 static thread_local std::string g_err;
@@ -172,9 +178,10 @@ extern "C" void yh_shutdown(yh_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     yh_comm_destroy(ctx);
-    if (ctx->stream) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamDestroy(ctx->stream);
+    for (hipStream_t st : {ctx->stream_c, ctx->stream}) {
+        if (!st) continue;
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamDestroy(st);
     }
     delete ctx;
 }
@@ -195,6 +202,7 @@ extern "C" int yh_device_info_get(yh_ctx* ctx, yh_device_info* out) {
 extern "C" int yh_wait(yh_ctx* ctx) {
     if (!ctx) return fail(nullptr, YH_ERR_BAD_ARG, "yh_wait: ctx is NULL");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stream_c) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
     return YH_OK;
 }
 
@@ -205,6 +213,7 @@ static void scene_free(yh_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->ctx->stream_c) (void)hipStreamSynchronize(s->ctx->stream_c);
     void* ptrs[] = {s->trs, s->lmat, s->world, s->parent, s->bounds, s->mesh_id, s->ldirty, s->wdirty, s->counts,
                     s->staging, s->d_all_counts, s->chg, s->chg_list};
     for (void* p : ptrs)
@@ -215,10 +224,13 @@ static void scene_free(yh_scene* s) {
         if (s->cmd[f]) (void)hipFree(s->cmd[f]);
         if (s->draw[f]) (void)hipFree(s->draw[f]);
         if (s->gathered[f]) (void)hipFree(s->gathered[f]);
+        if (s->padded[f]) (void)hipFree(s->padded[f]);
     }
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     if (s->h_chg) (void)hipHostFree(s->h_chg);
     if (s->h_all_counts) (void)hipHostFree(s->h_all_counts);
+    if (s->ev_frame) (void)hipEventDestroy(s->ev_frame);
+    if (s->ev_comm) (void)hipEventDestroy(s->ev_comm);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (hipEvent_t e : s->kev)
@@ -321,6 +333,7 @@ static int check_range(yh_scene* s, const char* who, uint64_t first, uint64_t co
 
 static int sync_scene(yh_scene* s) {
     HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
+    if (s->ctx->stream_c) HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream_c));
     s->frame_pending = false;
     return YH_OK;
 }
@@ -932,6 +945,10 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     s->root_dirty = 0;  // the world sweep clears the root's flag too
     if (cull) {
         // stage 3, part 2: tile prefix sums + expansion of the visibility words into ordered draw lists
+        if (s->comm_pending) {  // the previous frame's gather (other stream) still reads the lists and totals
+            HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_comm, 0));
+            s->comm_pending = false;
+        }
         ExpandArgs x;
         memset(&x, 0, sizeof x);
         x.vismask = s->vismask;
@@ -1391,6 +1408,7 @@ extern "C" int yh_comm_init(yh_ctx* ctx, int n_ranks, int rank, const void* uniq
     yh_nccl_id id;
     memcpy(&id, unique_id, sizeof id);
     RCCL_TRY(ctx, g_rccl.CommInitRank(&ctx->comm, n_ranks, id, rank));
+    if (!ctx->stream_c) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_c, hipStreamNonBlocking));
     ctx->n_ranks = n_ranks;
     ctx->rank = rank;
     return YH_OK;
@@ -1400,6 +1418,7 @@ extern "C" void yh_comm_destroy(yh_ctx* ctx) {
     if (ctx && ctx->comm && g_rccl.CommDestroy) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->stream_c) (void)hipStreamSynchronize(ctx->stream_c);
         g_rccl.CommDestroy(ctx->comm);
         ctx->comm = nullptr;
         ctx->n_ranks = 1;
@@ -1420,6 +1439,8 @@ extern "C" int yh_allgather_draw_lists(yh_scene* s, uint32_t* all_counts) {
         HIP_TRY(ctx, hipHostMalloc((void**)&s->h_all_counts, (size_t)R * YH_MAX_FRUSTA * 4, hipHostMallocDefault));
     }
     hipStream_t st = ctx->stream;
+    if (int rc = sync_scene(s)) return rc;  // a no-sync gather may still be in flight on the other stream
+    s->gathered_async = false;
     // (1) per-rank visible counts: 8 x u32 per rank
     RCCL_TRY(ctx, g_rccl.AllGather(s->counts, s->d_all_counts, YH_MAX_FRUSTA, /*ncclUint32*/ 3, ctx->comm, st));
     HIP_TRY(ctx, hipMemcpyAsync(s->h_all_counts, s->d_all_counts, (size_t)R * YH_MAX_FRUSTA * 4, hipMemcpyDeviceToHost, st));
@@ -1465,9 +1486,79 @@ extern "C" int yh_allgather_draw_lists(yh_scene* s, uint32_t* all_counts) {
     return YH_OK;
 }
 
+// The same exchange without a host round trip, for frames that are enqueued back to back: counts by ncclAllGather,
+// every list by an ncclAllGather padded to the list capacity, then one packing kernel per frustum — all on the
+// context's collective stream, behind this frame's launches and beside the next frame's transform launches (only the
+// next expansion, which rewrites the lists, waits for it).  Sends capacity instead of count entries per rank: worth it
+// while a frame is shorter than a host sync (measured: ~40 us frames at 1M entities per GPU).
+extern "C" int yh_allgather_draw_lists_async(yh_scene* s) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_allgather_draw_lists_async: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    if (!ctx->comm) return fail(ctx, YH_ERR_STATE, "yh_allgather_draw_lists_async: call yh_comm_init first");
+    if (s->frames == 0) return fail(ctx, YH_ERR_STATE, "yh_allgather_draw_lists_async: no frame has run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int R = ctx->n_ranks;
+    const uint32_t F = s->last_n_frusta;
+    if (!s->d_all_counts) {
+        HIP_TRY(ctx, hipMalloc((void**)&s->d_all_counts, (size_t)R * YH_MAX_FRUSTA * 4));
+        HIP_TRY(ctx, hipHostMalloc((void**)&s->h_all_counts, (size_t)R * YH_MAX_FRUSTA * 4, hipHostMallocDefault));
+    }
+    if (!s->ev_frame) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_frame, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming));
+    }
+    const uint64_t cap = s->draw_cap;
+    for (uint32_t f = 0; f < F; ++f) {
+        if (!s->padded[f]) HIP_TRY(ctx, hipMalloc((void**)&s->padded[f], (uint64_t)R * cap * 4));
+        if (s->gathered_cap[f] < (uint64_t)R * cap) {
+            if (int rc = sync_scene(s)) return rc;
+            if (s->gathered[f]) HIP_TRY(ctx, hipFree(s->gathered[f]));
+            s->gathered[f] = nullptr;
+            s->gathered_cap[f] = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&s->gathered[f], (uint64_t)R * cap * 4));
+            s->gathered_cap[f] = (uint64_t)R * cap;
+        }
+    }
+    hipStream_t sc = ctx->stream_c;
+    HIP_TRY(ctx, hipEventRecord(s->ev_frame, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(sc, s->ev_frame, 0));
+    RCCL_TRY(ctx, g_rccl.AllGather(s->counts, s->d_all_counts, YH_MAX_FRUSTA, /*ncclUint32*/ 3, ctx->comm, sc));
+    for (uint32_t f = 0; f < F; ++f) {
+        RCCL_TRY(ctx, g_rccl.AllGather(s->draw[f], s->padded[f], cap, /*ncclUint32*/ 3, ctx->comm, sc));
+        hipLaunchKernelGGL(k_compact_gathered, dim3(cdiv(cap, YH_BLOCK), R), dim3(YH_BLOCK), 0, sc, s->padded[f], s->d_all_counts, f,
+                           cap, s->gathered[f]);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(s->h_all_counts, s->d_all_counts, (size_t)R * YH_MAX_FRUSTA * 4, hipMemcpyDeviceToHost, sc));
+    HIP_TRY(ctx, hipEventRecord(s->ev_comm, sc));
+    s->comm_pending = true;
+    s->gathered_async = true;
+    s->frame_pending = true;
+    return YH_OK;
+}
+
+extern "C" int yh_get_gathered_counts(yh_scene* s, uint32_t* all_counts) {
+    if (!s || !all_counts) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_get_gathered_counts: NULL argument");
+    if (!s->h_all_counts) return fail(s->ctx, YH_ERR_STATE, "yh_get_gathered_counts: no gather has run");
+    if (int rc = sync_scene(s)) return rc;
+    const uint32_t F = s->last_n_frusta;
+    for (int r = 0; r < s->ctx->n_ranks; ++r)
+        for (uint32_t f = 0; f < F; ++f) all_counts[r * F + f] = s->h_all_counts[r * YH_MAX_FRUSTA + f];
+    return YH_OK;
+}
+
 extern "C" int yh_get_gathered_draw_list(yh_scene* s, uint32_t frustum, uint32_t* out, uint64_t cap, uint64_t* written) {
     if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_get_gathered_draw_list: scene is NULL");
     ARG_TRY(s->ctx, frustum < s->last_n_frusta, "yh_get_gathered_draw_list: frustum index out of range");
+    if (s->gathered_async) {  // lengths become known on the host only now
+        if (int rc = sync_scene(s)) return rc;
+        for (uint32_t f = 0; f < s->last_n_frusta; ++f) {
+            uint64_t total = 0;
+            for (int r = 0; r < s->ctx->n_ranks; ++r) total += std::min<uint64_t>(s->h_all_counts[r * YH_MAX_FRUSTA + f], s->draw_cap);
+            s->gathered_len[f] = total;
+        }
+        s->gathered_async = false;
+    }
     const uint64_t c = s->gathered_len[frustum];
     if (written) *written = c;
     if (c > cap || (c && !out))
