@@ -220,6 +220,11 @@ void yh_mat4_mul(const float a[16], const float b[16], float out[16]);          
 void yh_perspective(float fovy_rad, float aspect, float near_z, float far_z, float out[16]); /* :649-659 */
 void yh_orthographic(float l, float r, float b, float t, float n, float f, float out[16]);   /* :661-683 */
 void yh_look_at(const float eye[3], const float at[3], const float up[3], float out[16]);    /* :991-1021 */
+/* Camera.view_projection as the engine updates it (components/camera.zig:253-302): view =
+ * Rx*Ry*Rz*T(-pos) (Mat4.rotation, math3d.zig:687-710), perspective: rot in degrees, projection Y-flipped;
+ * orthographic: rot in radians, the engine's fixed +-10 box, depth 0..200.  Feed the result to yh_extract_planes. */
+void yh_camera_view_projection(int orthographic, const float pos[3], const float rot[3], float aspect, float fovy_rad,
+                               float near_z, float far_z, float view_projection_out[16]);
 
 /* ---- synthetic scenes (measurement harness) ---------------------------------------------- */
 typedef struct yh_synth_desc {

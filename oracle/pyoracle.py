@@ -87,6 +87,21 @@ def look_at(eye, at, up):
     return out
 
 
+def rotation(axis, angle_rad):
+    axis = _f32(axis)
+    out = np.empty(16, np.float32)
+    lib().yo_rotation(_p(axis), C.c_float(angle_rad), _p(out))
+    return out
+
+
+def camera_view_projection(orthographic, pos, rot, aspect=2.0, fovy_rad=1.3089969, near=0.1, far=200.0):
+    pos, rot = _f32(pos), _f32(rot)
+    out = np.empty(16, np.float32)
+    lib().yo_camera_view_projection(int(orthographic), _p(pos), _p(rot), C.c_float(aspect), C.c_float(fovy_rad),
+                                    C.c_float(near), C.c_float(far), _p(out))
+    return out
+
+
 def extract_planes(vp):
     vp = _f32(vp).reshape(16)
     out = np.empty(24, np.float32)

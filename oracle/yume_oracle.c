@@ -201,6 +201,55 @@ void yo_look_at(const float eye[3], const float at[3], const float up[3], yo_mat
     out->v[15] = 1.0f;
 }
 
+/* engine/math3d.zig:687-710.  @cos / @sin are libm's here; Zig lowers them to its own compiler-rt routines, so the
+ * trigonometric values themselves are "parity unpinned" (everything built from them follows the reference). */
+void yo_rotation(const float axis_in[3], float angle_rad, yo_mat4* out) {
+    float axis[3] = {axis_in[0], axis_in[1], axis_in[2]};
+    const float c = cosf(angle_rad), s = sinf(angle_rad);
+    const float t = 1.0f - c;
+    const float sqr_norm = axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2];
+    if (sqr_norm == 0.0f) {
+        yo_identity(out);
+        return;
+    }
+    if (fabsf(sqr_norm - 1.0f) > 0.0001f) {
+        const float norm = sqrtf(sqr_norm);
+        axis[0] = axis[0] / norm;
+        axis[1] = axis[1] / norm;
+        axis[2] = axis[2] / norm;
+    }
+    const float x = axis[0], y = axis[1], z = axis[2];
+    out->v[0] = x * x * t + c; out->v[1] = y * x * t + z * s; out->v[2] = z * x * t - y * s; out->v[3] = 0.0f;
+    out->v[4] = x * y * t - z * s; out->v[5] = y * y * t + c; out->v[6] = z * y * t + x * s; out->v[7] = 0.0f;
+    out->v[8] = x * z * t + y * s; out->v[9] = y * z * t - x * s; out->v[10] = z * z * t + c; out->v[11] = 0.0f;
+    out->v[12] = 0.0f; out->v[13] = 0.0f; out->v[14] = 0.0f; out->v[15] = 1.0f;
+}
+
+/* engine/components/camera.zig:253-302: view = Rx * Ry * Rz * T(-pos); perspective: angles in degrees, projection
+ * with unnamed[1][1] negated (Vulkan Y flip); orthographic: angles taken as radians, fixed +-10 box, depth 0..200;
+ * view_projection = projection * view. */
+void yo_camera_view_projection(int orthographic, const float pos[3], const float rot[3], float aspect, float fovy_rad,
+                               float near_z, float far_z, yo_mat4* out) {
+    const float rad_per_deg = 0.017453292519943295769f;
+    static const float ax[3] = {1.0f, 0.0f, 0.0f}, ay[3] = {0.0f, 1.0f, 0.0f}, az[3] = {0.0f, 0.0f, 1.0f};
+    yo_mat4 rx, ry, rz, tr, a, b, view, proj;
+    yo_rotation(ax, orthographic ? rot[0] : rot[0] * rad_per_deg, &rx);
+    yo_rotation(ay, orthographic ? rot[1] : rot[1] * rad_per_deg, &ry);
+    yo_rotation(az, orthographic ? rot[2] : rot[2] * rad_per_deg, &rz);
+    const float g[3] = {-pos[0], -pos[1], -pos[2]};
+    yo_translation(g, &tr);
+    yo_mul(&rx, &ry, &a);
+    yo_mul(&a, &rz, &b);
+    yo_mul(&b, &tr, &view);
+    if (orthographic) {
+        yo_orthographic(-10.0f, 10.0f, -10.0f, 10.0f, 0.0f, 200.0f, &proj);
+    } else {
+        yo_perspective(fovy_rad, aspect, near_z, far_z, &proj);
+        proj.v[5] *= -1.0f;
+    }
+    yo_mul(&proj, &view, out);
+}
+
 /* ----------------------------------------------------------------------------------------------- systems */
 
 /* engine/systems/TransformSyncSystem.zig:60-73, with the `Up` field read as one shared value (F4). */

@@ -48,6 +48,9 @@ void yo_compose(const float t[3], const float q[4], const float s[3], yo_mat4* o
 int yo_inverse(const yo_mat4* m, yo_mat4* out); /* 0 = DeterminantZero        math3d.zig:763-814 */
 void yo_perspective(float fovy_rad, float aspect, float near_z, float far_z, yo_mat4* out); /* :649-659 */
 void yo_orthographic(float l, float r, float b, float t, float n, float f, yo_mat4* out);   /* :661-683 */
+void yo_rotation(const float axis[3], float angle_rad, yo_mat4* out);          /* math3d.zig:687-710 */
+void yo_camera_view_projection(int orthographic, const float pos[3], const float rot[3], float aspect, float fovy_rad,
+                               float near_z, float far_z, yo_mat4* out);       /* components/camera.zig:253-302 */
 void yo_look_at(const float eye[3], const float at[3], const float up[3], yo_mat4* out);    /* :991-1021 */
 
 /* ---- systems ---- */

@@ -76,6 +76,33 @@ def test_host_helpers_match_oracle(oracle):
     assert np.array_equal(api.orthographic(-10, 10, -10, 10, 0, 200), oracle.orthographic(-10, 10, -10, 10, 0, 200))
     assert np.array_equal(synth.main_camera_planes(), oracle.main_camera_planes())
     assert np.array_equal(synth.cascade_planes(), oracle.cascade_planes())
+    # Camera.view_projection (camera.zig:253-302): library helper == oracle restatement, both camera kinds
+    for ortho in (0, 1):
+        for _ in range(10):
+            pos, rot = rng.uniform(-100, 100, 3), rng.uniform(-180, 180, 3) if not ortho else rng.uniform(-3, 3, 3)
+            a = api.camera_view_projection(ortho, pos, rot, 1.7, 1.2, 0.1, 500.0)
+            assert np.array_equal(a, oracle.camera_view_projection(ortho, pos, rot, 1.7, 1.2, 0.1, 500.0))
+
+
+def test_camera_view_projection_properties(oracle):
+    """Identities the reference's camera update implies (the trig values themselves are libm's: parity unpinned)."""
+    I = oracle.identity68()["m"][0]
+    assert np.array_equal(oracle.rotation([0, 0, 0], 1.0), I)            # zero axis -> IDENTITY (math3d.zig:693-694)
+    assert np.array_equal(oracle.rotation([0, 2, 0], 0.7), oracle.rotation([0, 1, 0], 0.7))  # axis is normalised
+    r = oracle.rotation([0, 0, 1], np.float32(np.pi / 2)).reshape(4, 4)  # columns
+    assert np.allclose(r[0][:3], [0, 1, 0], atol=1e-6) and np.allclose(r[1][:3], [-1, 0, 0], atol=1e-6)
+    # no rotation, camera at the origin: view = IDENTITY, so view_projection = projection with the Y flip
+    vp = oracle.camera_view_projection(0, [0, 0, 0], [0, 0, 0], 2.0, 1.3, 0.1, 200.0)
+    p = oracle.perspective(1.3, 2.0, 0.1, 200.0).copy()
+    p[5] *= -1
+    assert np.array_equal(vp, oracle.mul(p, I))
+    # a point straight ahead (-Z) of a camera moved to +10 z is inside all six planes; one behind it is not
+    planes = oracle.extract_planes(oracle.camera_view_projection(0, [0, 0, 10], [0, 0, 0])).reshape(6, 4)
+    inside = lambda q: bool(np.all(planes[:, :3] @ np.asarray(q, np.float32) + planes[:, 3] >= 0))
+    assert inside([0, 0, 0]) and not inside([0, 0, 20]) and not inside([0, 0, -500])
+    # orthographic: the engine's fixed +-10 box, depth 0..200, no Y flip
+    vo = oracle.camera_view_projection(1, [0, 0, 0], [0, 0, 0])
+    assert np.array_equal(vo, oracle.mul(oracle.orthographic(-10, 10, -10, 10, 0, 200), I))
 
 
 def test_harness_hierarchy_matches_oracle(oracle):

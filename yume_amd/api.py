@@ -354,6 +354,14 @@ def look_at(eye, at, up):
     return out
 
 
+def camera_view_projection(orthographic, pos, rot, aspect=2.0, fovy_rad=1.3089969, near=0.1, far=200.0):
+    """Camera.view_projection as engine/components/camera.zig:253-302 updates it."""
+    pos, rot = (np.ascontiguousarray(v, np.float32) for v in (pos, rot))
+    out = np.empty(16, np.float32)
+    L.lib().yh_camera_view_projection(int(orthographic), _ptr(pos), _ptr(rot), aspect, fovy_rad, near, far, _ptr(out))
+    return out
+
+
 def extract_planes(view_projection):
     vp = np.ascontiguousarray(view_projection, np.float32).reshape(16)
     out = np.empty(24, np.float32)

@@ -1228,6 +1228,53 @@ extern "C" void yh_look_at(const float eye[3], const float at[3], const float up
     memcpy(out, m, 64);
 }
 
+// engine/math3d.zig:687-710 (host libm cos / sin; Zig uses its own routines, so the trig values are not pinned)
+static void h_rotation(const float axis_in[3], float angle_rad, float out[16]) {
+    float axis[3] = {axis_in[0], axis_in[1], axis_in[2]};
+    const float c = cosf(angle_rad), s = sinf(angle_rad);
+    const float t = 1.0f - c;
+    const float sqr_norm = axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2];
+    if (sqr_norm == 0.0f) {
+        for (int i = 0; i < 16; ++i) out[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+        return;
+    }
+    if (fabsf(sqr_norm - 1.0f) > 0.0001f) {
+        const float norm = sqrtf(sqr_norm);
+        for (int i = 0; i < 3; ++i) axis[i] = axis[i] / norm;
+    }
+    const float x = axis[0], y = axis[1], z = axis[2];
+    const float m[16] = {x * x * t + c, y * x * t + z * s, z * x * t - y * s, 0.0f,
+                         x * y * t - z * s, y * y * t + c, z * y * t + x * s, 0.0f,
+                         x * z * t + y * s, y * z * t - x * s, z * z * t + c, 0.0f,
+                         0.0f, 0.0f, 0.0f, 1.0f};
+    memcpy(out, m, 64);
+}
+
+// engine/components/camera.zig:253-302: Camera.view_projection from the camera's position and Euler angles.
+extern "C" void yh_camera_view_projection(int orthographic, const float pos[3], const float rot[3], float aspect,
+                                          float fovy_rad, float near_z, float far_z, float out[16]) {
+    const float rad_per_deg = 0.017453292519943295769f;
+    const float ax[3] = {1.0f, 0.0f, 0.0f}, ay[3] = {0.0f, 1.0f, 0.0f}, az[3] = {0.0f, 0.0f, 1.0f};
+    float rx[16], ry[16], rz[16], tr[16], a[16], b[16], view[16], proj[16];
+    h_rotation(ax, orthographic ? rot[0] : rot[0] * rad_per_deg, rx);
+    h_rotation(ay, orthographic ? rot[1] : rot[1] * rad_per_deg, ry);
+    h_rotation(az, orthographic ? rot[2] : rot[2] * rad_per_deg, rz);
+    for (int i = 0; i < 16; ++i) tr[i] = (i % 5 == 0) ? 1.0f : 0.0f;  // Mat4.translation(-pos), math3d.zig:628-635
+    tr[12] = -pos[0];
+    tr[13] = -pos[1];
+    tr[14] = -pos[2];
+    yh_mat4_mul(rx, ry, a);
+    yh_mat4_mul(a, rz, b);
+    yh_mat4_mul(b, tr, view);
+    if (orthographic) {
+        yh_orthographic(-10.0f, 10.0f, -10.0f, 10.0f, 0.0f, 200.0f, proj);
+    } else {
+        yh_perspective(fovy_rad, aspect, near_z, far_z, proj);
+        proj[5] *= -1.0f;  // camera.zig:272
+    }
+    yh_mat4_mul(proj, view, out);
+}
+
 // Gribb-Hartmann, depth 0..1: L,R,B,T,N,F, each divided by |n|.
 extern "C" void yh_extract_planes(const float vp[16], float planes_out[24]) {
     float p[6][4];

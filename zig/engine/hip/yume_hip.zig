@@ -65,6 +65,10 @@ pub extern fn yh_get_counts(s: *Scene, counts: [*]u32, boundary_counts: ?[*]u32)
 pub extern fn yh_get_draw_list(s: *Scene, frustum: u32, out: [*]u32, cap: u64, written: *u64) c_int;
 pub extern fn yh_download_world_aos68(s: *Scene, column: *anyopaque, first: u64, count: u64) c_int;
 pub extern fn yh_download_local_aos68(s: *Scene, column: *anyopaque, first: u64, count: u64) c_int;
+pub extern fn yh_camera_view_projection(orthographic: c_int, pos: *const [3]f32, rot: *const [3]f32, aspect: f32, fovy_rad: f32, near_z: f32, far_z: f32, out: *[16]f32) void;
+pub extern fn yh_upload_vertex_counts(s: *Scene, counts: [*]const u32, n: u64) c_int;
+pub extern fn yh_build_object_data(s: *Scene, frustum: u32, batch_offset: u32) c_int;
+pub extern fn yh_object_data_device(s: *Scene, frustum: u32, cmds_device: ?*?*anyopaque) ?*anyopaque;
 pub extern fn yh_extract_planes(view_projection: *const [16]f32, planes: *[24]f32) void;
 
 pub fn check(rc: c_int) !void {
