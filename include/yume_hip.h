@@ -189,6 +189,11 @@ int yh_build_object_data(yh_scene* s, uint32_t frustum, uint32_t batch_offset);
 int yh_get_object_data(yh_scene* s, uint32_t frustum, void* model_matrices, yh_draw_cmd* cmds, uint64_t cap,
                        uint64_t* written);
 void* yh_object_data_device(yh_scene* s, uint32_t frustum, void** cmds_device);
+/* Batched Mat4.decompose (math3d.zig:828-981) of the world (which = 0) or local (which = 1, Mat4
+ * scenes) matrices: what the position() / rotation() / scale() accessors compute one row at a time
+ * (components/transform.zig:14-28, 68-82).  planes: t.xyz, q.xyzw, s.xyz on the host; valid (optional): 0 where the
+ * reference returns error.InvalidMatrix and the accessors substitute Decomposed.IDENTITY, which is what is written. */
+int yh_decompose(yh_scene* s, int which, float* const planes[10], uint8_t* valid, uint64_t first, uint64_t count);
 /* Stage 1 alone: Mat4.compose over a range, result as 16 SoA planes on the host (testing aid).          */
 int yh_compose(yh_scene* s, float* const planes[16], uint64_t first, uint64_t count);
 

@@ -126,6 +126,16 @@ def compose_batch(trs):
     return out
 
 
+def decompose_batch(column):
+    """(n,) T68 -> ((10, n) f32 planes t.xyz q.xyzw s.xyz, (n,) u8 valid): decompose() catch IDENTITY per row."""
+    assert column.dtype == T68
+    n = column.shape[0]
+    trs = np.zeros((10, n), np.float32)
+    valid = np.zeros(n, np.uint8)
+    lib().yo_decompose_batch(_p(np.ascontiguousarray(column)), C.c_size_t(n), _p(trs), C.c_size_t(n), _p(valid))
+    return trs, valid
+
+
 def transform_sync_batch(world, local, parent):
     """TransformSyncSystem.zig:53-74 on one table batch (in place); parent: (1,) T68."""
     assert world.dtype == T68 and local.dtype == T68 and parent.dtype == T68

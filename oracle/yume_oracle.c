@@ -339,6 +339,117 @@ void yo_compose_batch(const float* trs, size_t stride, size_t first, size_t coun
     }
 }
 
+/* engine/math3d.zig:828-981 (Mat4.decompose; determinant3x3 :984-988; Vec3 helpers :80-156; epsilonEql :1113-1119,
+ * epsilon = floatEps(f32)).  unnamed[i][j] = values[i*4+j]: the function's "rows" are the matrix columns.  The
+ * perspective vector it solves for is never returned, so only that branch's side effect is kept (the perspective
+ * partition is cleared).  Returns 0 where the reference returns error.InvalidMatrix. */
+#define YO_EPS 1.1920928955078125e-07f
+static int eps_eql(float a, float b) { return fabsf(a - b) <= YO_EPS; }
+static float v3_len(const float v[3]) { return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+static void v3_norm_zero(float v[3]) { /* Vec3.normalized: zero vector when the length is not > 0 */
+    const float l = v3_len(v);
+    if (l > 0.0f) {
+        v[0] = v[0] / l; v[1] = v[1] / l; v[2] = v[2] / l;
+    } else {
+        v[0] = v[1] = v[2] = 0.0f;
+    }
+}
+static void v3_combine(float v[3], const float o[3], float sv, float so) {
+    v[0] = v[0] * sv + o[0] * so; v[1] = v[1] * sv + o[1] * so; v[2] = v[2] * sv + o[2] * so;
+}
+int yo_decompose(const yo_mat4* in, float t[3], float q[4], float sc[3]) {
+    float m[16];
+    memcpy(m, in->v, sizeof m);
+    if (eps_eql(m[15], 0.0f)) return 0;
+    const float w = m[15];
+    for (int i = 0; i < 15; ++i) m[i] /= w;
+    m[15] /= m[15];
+    const float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) +
+                      m[2] * (m[4] * m[9] - m[5] * m[8]);
+    if (eps_eql(det, 0.0f)) return 0;
+    if (!eps_eql(m[3], 0.0f) || !eps_eql(m[7], 0.0f) || !eps_eql(m[11], 0.0f)) {
+        m[3] = m[7] = m[11] = 0.0f;
+        m[15] = 1.0f;
+    }
+    t[0] = m[12]; t[1] = m[13]; t[2] = m[14];
+    float row[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) row[i][j] = m[i * 4 + j];
+    sc[0] = v3_len(row[0]);
+    v3_norm_zero(row[0]);
+    float skew_z = v3_dot(row[0], row[1]);
+    v3_combine(row[1], row[0], 1.0f, -skew_z);
+    sc[1] = v3_len(row[1]);
+    if (eps_eql(sc[1], 0.0f)) return 0;
+    v3_norm_zero(row[1]);
+    float skew_y = v3_dot(row[0], row[2]);
+    v3_combine(row[2], row[0], 1.0f, -skew_y);
+    float skew_x = v3_dot(row[1], row[2]);
+    v3_combine(row[2], row[1], 1.0f, -skew_x);
+    sc[2] = v3_len(row[2]);
+    if (eps_eql(sc[2], 0.0f)) return 0;
+    v3_norm_zero(row[2]);
+    float pdum3[3];
+    v3_cross(row[1], row[2], pdum3);
+    if (v3_dot(row[0], pdum3) < 0.0f) {
+        for (int i = 0; i < 3; ++i) {
+            sc[i] *= -1.0f;
+            row[i][0] = row[i][0] * -1.0f; row[i][1] = row[i][1] * -1.0f; row[i][2] = row[i][2] * -1.0f;
+        }
+    }
+    const float trace = row[0][0] + row[1][1] + row[2][2];
+    if (trace > 0.0f) {
+        float root = sqrtf(trace + 1.0f);
+        q[3] = 0.5f * root;
+        root = 0.5f / root;
+        q[0] = root * (row[1][2] - row[2][1]);
+        q[1] = root * (row[2][0] - row[0][2]);
+        q[2] = root * (row[0][1] - row[1][0]);
+    } else {
+        static const int next[3] = {1, 2, 0};
+        int i = 0;
+        if (row[1][1] > row[0][0]) i = 1;
+        if (row[2][2] > row[i][i]) i = 2;
+        const int j = next[i], k = next[j];
+        float root = sqrtf(row[i][i] - row[j][j] - row[k][k] + 1.0f);
+        q[i] = 0.5f * root;
+        root = 0.5f / root;
+        if (i == 0) {
+            q[1] = root * (row[0][1] + row[1][0]);
+            q[2] = root * (row[0][2] + row[2][0]);
+            q[3] = root * (row[1][2] - row[2][1]);
+        } else if (i == 1) {
+            q[0] = root * (row[0][1] + row[1][0]);
+            q[2] = root * (row[1][2] + row[2][1]);
+            q[3] = root * (row[2][0] - row[0][2]);
+        } else {
+            q[0] = root * (row[0][2] + row[2][0]);
+            q[1] = root * (row[1][2] + row[2][1]);
+            q[3] = root * (row[0][1] - row[1][0]);
+        }
+    }
+    (void)skew_x; (void)skew_y; (void)skew_z; /* skew_* /= sc_* in the reference: results are discarded there too */
+    return 1;
+}
+
+/* The accessors' use of it (components/transform.zig:14-28, 68-82): `decompose() catch Decomposed.IDENTITY`, over
+ * a column.  Output: 10 planes t.xyz, q.xyzw, s.xyz of `stride` floats; valid[i] = 0 where IDENTITY was substituted. */
+void yo_decompose_batch(const yo_transform68* column, size_t count, float* trs, size_t stride, uint8_t* valid) {
+    for (size_t i = 0; i < count; ++i) {
+        float t[3], q[4], s[3];
+        const int ok = yo_decompose(&column[i].matrix, t, q, s);
+        if (!ok) {
+            t[0] = t[1] = t[2] = 0.0f;
+            q[0] = q[1] = q[2] = 0.0f; q[3] = 1.0f;
+            s[0] = s[1] = s[2] = 1.0f;
+        }
+        for (int c = 0; c < 3; ++c) trs[(size_t)c * stride + i] = t[c];
+        for (int c = 0; c < 4; ++c) trs[(size_t)(3 + c) * stride + i] = q[c];
+        for (int c = 0; c < 3; ++c) trs[(size_t)(7 + c) * stride + i] = s[c];
+        if (valid) valid[i] = (uint8_t)ok;
+    }
+}
+
 /* ----------------------------------------------------------------------------------------------- culling */
 
 /* Build-defined.  Rows of VP: row_r = (v[r], v[4+r], v[8+r], v[12+r]).

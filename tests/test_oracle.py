@@ -243,3 +243,44 @@ def test_golden_fixtures(oracle, name):
     for k in g.files:
         if k.startswith("vis") or k.startswith("bnd"):
             assert np.array_equal(got[k], g[k]), k
+
+
+def test_decompose_inverts_compose_and_flags_invalid_matrices(oracle):
+    """Mat4.decompose (math3d.zig:828-981): recovers T, R (up to sign), S of Mat4.compose for positive scales; negative
+    determinants come back with all three scales negated; singular matrices and w = 0 are InvalidMatrix -> IDENTITY."""
+    rng = np.random.default_rng(3)
+    n = 2000
+    t = rng.uniform(-100, 100, (3, n)).astype(np.float32)
+    q = rng.uniform(-1, 1, (4, n)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=0, keepdims=True).astype(np.float32)
+    s = rng.uniform(0.2, 3, (3, n)).astype(np.float32)
+    col = oracle.compose_batch(np.concatenate([t, q, s]))
+    d, valid = oracle.decompose_batch(col)
+    assert valid.all()
+    assert np.allclose(d[0:3], t, rtol=0, atol=0)  # the translation column is copied (divided by w = 1)
+    assert np.allclose(d[7:10], s, rtol=2e-5)
+    sign = np.sign((d[3:7] * q).sum(axis=0))
+    assert np.allclose(d[3:7] * sign, q, atol=2e-5)
+    # recompose(decompose(M)) == M up to rounding (math3d.zig:824-826)
+    back = oracle.compose_batch(d)
+    assert np.allclose(back["m"], col["m"], rtol=1e-4, atol=1e-4)
+    # mirrored: one negative scale -> determinant < 0 -> every scale negated, rotation still proper
+    m = col[:100].copy()
+    m["m"][:, 0:3] *= -1
+    dm, vm = oracle.decompose_batch(m)
+    assert vm.all() and (dm[7:10] < 0).all()
+    # invalid: zero scale on an axis (singular 3x3), w = 0
+    bad = col[:4].copy()
+    bad["m"][0, 4:7] = 0
+    bad["m"][1, 15] = 0
+    bad["m"][2, :] = 0
+    db, vb = oracle.decompose_batch(bad)
+    assert vb.tolist() == [0, 0, 0, 1]
+    for i in range(3):
+        assert db[:, i].tolist() == [0, 0, 0, 0, 0, 0, 1, 1, 1, 1]
+    # a perspective partition is cleared, w != 1 divides everything first
+    p = col[:1].copy()
+    p["m"][0] *= 2.0
+    p["m"][0, 3] = 0.25
+    dp, vp = oracle.decompose_batch(p)
+    assert vp[0] == 1 and np.allclose(dp[0:3, 0], t[:, 0], rtol=1e-6) and np.allclose(dp[7:10, 0], s[:, 0], rtol=2e-5)

@@ -217,6 +217,14 @@ class Scene:
         self._ck(L.lib().yh_download_local_aos68(self._h, _ptr(out), first, count))
         return out
 
+    def decompose(self, which="world", first=0, count=None):
+        """Batched Mat4.decompose: ((10, count) planes t.xyz q.xyzw s.xyz, (count,) u8 valid)."""
+        count = self.n - first if count is None else count
+        out = np.zeros((10, count), np.float32)
+        valid = np.zeros(count, np.uint8)
+        self._ck(L.lib().yh_decompose(self._h, 0 if which == "world" else 1, _plane_ptrs(out), _ptr(valid), first, count))
+        return out, valid
+
     # ---- draw-list consumer ----
     def upload_vertex_counts(self, counts):
         counts = np.ascontiguousarray(counts, np.uint32)

@@ -488,6 +488,27 @@ __global__ __launch_bounds__(YH_BLOCK) void k_compose(const float* __restrict__ 
     for (int q = 0; q < 16; ++q) out[(uint64_t)q * out_stride + i] = l.v[q];
 }
 
+// Batched Mat4.decompose over a chunked matrix array: what the position() / rotation() / scale()
+// accessors compute per call (components/transform.zig:14-28, 68-82: `decompose() catch Decomposed.IDENTITY`).
+// out: 10 plain planes of out_stride floats; valid: 1 where the matrix decomposed, 0 where IDENTITY was substituted.
+__global__ __launch_bounds__(YH_BLOCK) void k_decompose(const float* __restrict__ arr, float* __restrict__ out,
+                                                        uint8_t* __restrict__ valid, uint64_t out_stride, uint64_t first,
+                                                        uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;
+    if (i >= count) return;
+    M4 m;
+    load_row<16>(arr, (uint32_t)(first + i), m.v);
+    float d[10];
+    const bool ok = m4_decompose(m, d);
+    if (!ok) {
+        d[0] = d[1] = d[2] = d[3] = d[4] = d[5] = 0.0f;
+        d[6] = d[7] = d[8] = d[9] = 1.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) out[(uint64_t)q * out_stride + i] = d[q];
+    valid[i] = ok ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // flecs column import/export: 68-byte rows {f32 m[16]; u8 dirty; u8 pad[3]} (transform.zig:8-12) <-> chunked
 // planes.  A workgroup moves 256 rows = 4352 dwords with coalesced dword accesses on the AoS side and

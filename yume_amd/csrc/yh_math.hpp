@@ -134,6 +134,121 @@ YH_HD bool m4_inverse(const M4& m, M4& out) {
     return true;
 }
 
+// engine/math3d.zig:828-981 — Mat4.decompose (determinant3x3 :984-988, Vec3 helpers :80-156, epsilonEql :1113-1119).
+// unnamed[i][j] = values[i*4+j]: the function's "rows" are the matrix columns.  The perspective vector it solves for
+// is never returned; only that branch's side effect (the perspective partition is cleared) is kept.  Every operation
+// is a correctly rounded IEEE add / mul / div / sqrt (see the Makefile flags), in the reference's order.  Returns
+// false where the reference returns error.InvalidMatrix.  out: t.xyz, q.xyzw, s.xyz.
+YH_HD bool m4_decompose(const M4& in, float (&out)[10]) {
+    const float eps = 1.1920928955078125e-07f;
+    auto eql0 = [&](float a) { return __builtin_fabsf(a - 0.0f) <= eps; };
+    auto len3 = [](const float* v) { return __builtin_sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
+    auto dot3 = [](const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    auto normalize3 = [&](float* v) {
+        const float l = len3(v);
+        if (l > 0.0f) {
+            v[0] = v[0] / l;
+            v[1] = v[1] / l;
+            v[2] = v[2] / l;
+        } else {
+            v[0] = v[1] = v[2] = 0.0f;
+        }
+    };
+    auto combine3 = [](float* v, const float* o, float sv, float so) {
+        v[0] = v[0] * sv + o[0] * so;
+        v[1] = v[1] * sv + o[1] * so;
+        v[2] = v[2] * sv + o[2] * so;
+    };
+    float m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = in.v[i];
+    if (eql0(m[15])) return false;
+    const float w = m[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) m[i] = m[i] / w;
+    m[15] = m[15] / m[15];
+    const float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+    if (eql0(det)) return false;
+    if (!eql0(m[3]) || !eql0(m[7]) || !eql0(m[11])) {
+        m[3] = m[7] = m[11] = 0.0f;
+        m[15] = 1.0f;
+    }
+    float r0[3] = {m[0], m[1], m[2]}, r1[3] = {m[4], m[5], m[6]}, r2[3] = {m[8], m[9], m[10]};
+    float sx = len3(r0);
+    normalize3(r0);
+    const float skew_z = dot3(r0, r1);
+    combine3(r1, r0, 1.0f, -skew_z);
+    float sy = len3(r1);
+    if (eql0(sy)) return false;
+    normalize3(r1);
+    const float skew_y = dot3(r0, r2);
+    combine3(r2, r0, 1.0f, -skew_y);
+    const float skew_x = dot3(r1, r2);
+    combine3(r2, r1, 1.0f, -skew_x);
+    float sz = len3(r2);
+    if (eql0(sz)) return false;
+    normalize3(r2);
+    const float p[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+    if (dot3(r0, p) < 0.0f) {
+        sx *= -1.0f;
+        sy *= -1.0f;
+        sz *= -1.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            r0[c] = r0[c] * -1.0f;
+            r1[c] = r1[c] * -1.0f;
+            r2[c] = r2[c] * -1.0f;
+        }
+    }
+    float qx, qy, qz, qw;
+    const float trace = r0[0] + r1[1] + r2[2];
+    if (trace > 0.0f) {
+        float root = __builtin_sqrtf(trace + 1.0f);
+        qw = 0.5f * root;
+        root = 0.5f / root;
+        qx = root * (r1[2] - r2[1]);
+        qy = root * (r2[0] - r0[2]);
+        qz = root * (r0[1] - r1[0]);
+    } else {
+        int i = 0;
+        if (r1[1] > r0[0]) i = 1;
+        if (r2[2] > (i == 0 ? r0[0] : r1[1])) i = 2;
+        if (i == 0) {
+            float root = __builtin_sqrtf(r0[0] - r1[1] - r2[2] + 1.0f);
+            qx = 0.5f * root;
+            root = 0.5f / root;
+            qy = root * (r0[1] + r1[0]);
+            qz = root * (r0[2] + r2[0]);
+            qw = root * (r1[2] - r2[1]);
+        } else if (i == 1) {
+            float root = __builtin_sqrtf(r1[1] - r2[2] - r0[0] + 1.0f);
+            qy = 0.5f * root;
+            root = 0.5f / root;
+            qx = root * (r0[1] + r1[0]);
+            qz = root * (r1[2] + r2[1]);
+            qw = root * (r2[0] - r0[2]);
+        } else {
+            float root = __builtin_sqrtf(r2[2] - r0[0] - r1[1] + 1.0f);
+            qz = 0.5f * root;
+            root = 0.5f / root;
+            qx = root * (r0[2] + r2[0]);
+            qy = root * (r1[2] + r2[1]);
+            qw = root * (r0[1] - r1[0]);
+        }
+    }
+    out[0] = m[12];
+    out[1] = m[13];
+    out[2] = m[14];
+    out[3] = qx;
+    out[4] = qy;
+    out[5] = qz;
+    out[6] = qw;
+    out[7] = sx;
+    out[8] = sy;
+    out[9] = sz;
+    return true;
+}
+
 // ---- culling (build-defined) -------------------------------------------------------
 // Box centre c = (min+max)*0.5, half extents h = (max-min)*0.5, world centre cw = M*(c,1) in mulVec4 order
 // (engine/math3d.zig:612-620).  Per plane (n,d): s = n.cw + d, r = |n.M.i|*h.x + |n.M.j|*h.y + |n.M.k|*h.z.

@@ -748,6 +748,33 @@ extern "C" int yh_compose(yh_scene* s, float* const planes[16], uint64_t first, 
     return YH_OK;
 }
 
+// batched Mat4.decompose of the world (which = 0) or local (which = 1, Mat4 scenes) matrices.
+extern "C" int yh_decompose(yh_scene* s, int which, float* const planes[10], uint8_t* valid, uint64_t first, uint64_t count) {
+    if (int rc = check_range(s, "yh_decompose", first, count)) return rc;
+    ARG_TRY(s->ctx, planes, "yh_decompose: planes is NULL");
+    ARG_TRY(s->ctx, which == 0 || which == 1, "yh_decompose: which must be 0 (world) or 1 (local)");
+    const float* arr = which == 0 ? s->world : s->lmat;
+    if (!arr) return fail(s->ctx, YH_ERR_STATE, "yh_decompose: scene holds TRS locals");
+    for (int p = 0; p < 10; ++p) ARG_TRY(s->ctx, planes[p], "yh_decompose: plane pointer is NULL");
+    if (count == 0) return YH_OK;
+    HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
+    if (int rc = sync_scene(s)) return rc;
+    const uint64_t chunk = std::min<uint64_t>(count, YH_AOS_CHUNK);
+    if (int rc = ensure_staging(s, chunk * 41)) return rc;  // 10 f32 planes + the validity bytes
+    uint8_t* d_valid = (uint8_t*)s->staging + chunk * 40;
+    for (uint64_t done = 0; done < count; done += chunk) {
+        const uint64_t c = std::min<uint64_t>(chunk, count - done);
+        hipLaunchKernelGGL(k_decompose, dim3(cdiv(c, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream, arr, (float*)s->staging,
+                           d_valid, chunk, first + done, c);
+        HIP_TRY(s->ctx, hipGetLastError());
+        HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
+        for (int p = 0; p < 10; ++p)
+            HIP_TRY(s->ctx, hipMemcpy(planes[p] + done, (float*)s->staging + (uint64_t)p * chunk, c * 4, hipMemcpyDeviceToHost));
+        if (valid) HIP_TRY(s->ctx, hipMemcpy(valid + done, d_valid, c, hipMemcpyDeviceToHost));
+    }
+    return YH_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ frame
 template <int BOUNDS>
 static void launch_trs(bool has_base, dim3 grid, hipStream_t st, const FrameArgs& a) {
