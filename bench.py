@@ -133,7 +133,7 @@ def kernel_symbol(levels_in_group, bounds, has_base):
     """Name rocprofv3 reports for the launch of a level group (yume_hip.hip launch_trs / launch_chain)."""
     hb = "true" if has_base else "false"
     if levels_in_group == 1:
-        return f"void k_frame_trs<{bounds}, {hb}, false>(FrameArgs)"
+        return f"void k_frame_trs<{bounds}, {hb}>(FrameArgs)"
     g = next(x for x in (2, 3, 4, 6, 8) if levels_in_group <= x)
     return f"void k_frame_chain<{g}, {bounds}, {hb}>(FrameArgs)"
 

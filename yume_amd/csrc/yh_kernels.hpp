@@ -23,7 +23,6 @@
 
 #define YH_K_MAX_FRUSTA 8
 #define YH_BLOCK 256
-#define YH_MAX_ITERS 8 /* a workgroup handles iters x 256 consecutive entities */
 #define YH_MAX_GROUP 8 /* levels one launch may span (k_frame_chain) */
 #define YH_CHUNK 64
 
@@ -44,7 +43,6 @@ struct FrameArgs {
     uint32_t n_frusta;
     uint32_t id_base;
     uint32_t n_meshes;
-    uint32_t iters;  // 256-entity slices per workgroup (1..YH_MAX_ITERS)
     float root[16];
     float planes[YH_K_MAX_FRUSTA * 24];
 };
@@ -143,56 +141,35 @@ __device__ __forceinline__ void load_inputs(const FrameArgs& a, uint32_t e, TrsI
 // Fused frame kernel, TRS locals, every LocalTransform dirty (forward branch of
 // TransformSyncSystem.zig:67-68 on every row), ONE level per launch:
 //   stage 1: Mat4.compose   stage 2: W = W_parent * L   stage 3: cull + visibility ballot.
-// A workgroup walks `iters` slices of 256 consecutive entities; with PREFETCH the streamed inputs of slice
-// i+1 are requested before slice i is computed (register double buffer).  BOUNDS: 0 none, 1 per-entity
-// planes, 2 mesh table.  HAS_BASE: the level is > 0 (its entities have stored parents), else the parent
-// is the scene root.
-template <int BOUNDS, bool HAS_BASE, bool PREFETCH>
+// One entity per lane, one 64-entity chunk per wave, 256 entities per workgroup (more slices per workgroup and a
+// register double buffer of the next slice's inputs were measured and dropped: DESIGN.md §4).  BOUNDS: 0 none,
+// 1 per-entity planes, 2 mesh table.  HAS_BASE: the level is > 0 (its entities have stored parents), else the
+// parent is the scene root.
+template <int BOUNDS, bool HAS_BASE>
 __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs(const FrameArgs a) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t tile = a.iters * YH_BLOCK;
     // chunk-aligned mapping: every wave covers exactly one 64-entity chunk of the arrays
-    const uint64_t tile0 = (uint64_t)(a.begin & ~63u) + (uint64_t)blockIdx.x * tile;
-    const uint32_t last = a.end - 1;
+    const uint64_t e64 = (uint64_t)(a.begin & ~63u) + (uint64_t)blockIdx.x * YH_BLOCK + tid;
+    if (e64 - (tid & 63u) >= a.end) return;  // this wave's chunk starts past the end (wave-uniform)
+    const bool valid = e64 >= a.begin && e64 < a.end;
     // lanes outside [begin, end) redo a valid entity of the launch and store nothing
-    auto clamp_e = [&](uint64_t e64) -> uint32_t { return e64 < a.begin ? a.begin : (e64 < a.end ? (uint32_t)e64 : last); };
-
-    TrsInputs<BOUNDS> cur;
-    if (PREFETCH) load_inputs<BOUNDS, HAS_BASE, true>(a, clamp_e(tile0 + tid), cur);
-#pragma unroll 1
-    for (uint32_t it = 0; it < a.iters; ++it) {
-        const uint64_t e64 = tile0 + (uint64_t)it * YH_BLOCK + tid;
-        if (e64 - tid + (tid & ~63u) >= a.end) break;  // this wave's chunk starts past the end (wave-uniform)
-        const bool valid = e64 >= a.begin && e64 < a.end;
-        const uint32_t e = clamp_e(e64);
-        TrsInputs<BOUNDS> nxt;
-        if (PREFETCH) {
-            nxt = cur;
-            if (it + 1 < a.iters) load_inputs<BOUNDS, HAS_BASE, true>(a, clamp_e(e64 + YH_BLOCK), nxt);
-        } else {
-            load_inputs<BOUNDS, HAS_BASE, true>(a, e, cur);
-        }
-        M4 w;
-        if (HAS_BASE) {
-            load_row<16>(a.world, cur.pidx, w.v);
-        } else {
+    const uint32_t e = e64 < a.begin ? a.begin : (e64 < a.end ? (uint32_t)e64 : a.end - 1u);
+    TrsInputs<BOUNDS> in;
+    load_inputs<BOUNDS, HAS_BASE, true>(a, e, in);
+    M4 w;
+    if (HAS_BASE) {
+        load_row<16>(a.world, in.pidx, w.v);
+    } else {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) w.v[q] = a.root[q];
-        }
-        {
-            const M4 l = m4_compose(cur.t[0], cur.t[1], cur.t[2], cur.t[3], cur.t[4], cur.t[5], cur.t[6], cur.t[7],
-                                    cur.t[8], cur.t[9]);
-            w = m4_mul(w, l);
-        }
-        if (valid) store_row<16>(a.world, e, w.v);
-        if (BOUNDS != 0) {
-            uint32_t vmask = 0, bmask = 0;
-            cull_entity<BOUNDS>(a, w, cur.b, cur.mesh, vmask, bmask);
-            if (!valid) vmask = bmask = 0;
-            const uint64_t c0 = e64 - (tid & 63u);  // first entity of this wave's chunk
-            publish_visible(a, (uint32_t)(e64 >> 6), c0 < a.begin, vmask, bmask);
-        }
-        if (PREFETCH) cur = nxt;
+        for (int q = 0; q < 16; ++q) w.v[q] = a.root[q];
+    }
+    w = m4_mul(w, m4_compose(in.t[0], in.t[1], in.t[2], in.t[3], in.t[4], in.t[5], in.t[6], in.t[7], in.t[8], in.t[9]));
+    if (valid) store_row<16>(a.world, e, w.v);
+    if (BOUNDS != 0) {
+        uint32_t vmask = 0, bmask = 0;
+        cull_entity<BOUNDS>(a, w, in.b, in.mesh, vmask, bmask);
+        if (!valid) vmask = bmask = 0;
+        publish_visible(a, (uint32_t)(e64 >> 6), e64 - (tid & 63u) < a.begin, vmask, bmask);
     }
 }
 
@@ -261,65 +238,56 @@ __global__ __launch_bounds__(YH_BLOCK) void k_frame_chain(const FrameArgs a) {
 template <int BOUNDS, bool HAS_BASE>
 __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, const uint32_t root_dirty) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t tile = a.iters * YH_BLOCK;
-    const uint64_t tile0 = (uint64_t)(a.begin & ~63u) + (uint64_t)blockIdx.x * tile;
-
-#pragma unroll 1
-    for (uint32_t it = 0; it < a.iters; ++it) {
-        const uint64_t e64 = tile0 + (uint64_t)it * YH_BLOCK + tid;
-        if (e64 - tid + (tid & ~63u) >= a.end) break;  // wave-uniform
-        const bool valid = e64 >= a.begin && e64 < a.end;
-        const uint32_t e = (uint32_t)e64;
-        uint32_t vmask = 0, bmask = 0;
-        if (valid) {
-            uint32_t bp = 0;
-            bool pd;
+    const uint64_t e64 = (uint64_t)(a.begin & ~63u) + (uint64_t)blockIdx.x * YH_BLOCK + tid;
+    if (e64 - (tid & 63u) >= a.end) return;  // this wave's chunk starts past the end (wave-uniform)
+    const bool valid = e64 >= a.begin && e64 < a.end;
+    const uint32_t e = (uint32_t)e64;
+    uint32_t vmask = 0, bmask = 0;
+    if (valid) {
+        uint32_t bp = 0;
+        bool pd;
+        if (HAS_BASE) {
+            bp = a.parent[e];
+            pd = a.wdirty[bp] != 0;
+        } else {
+            pd = root_dirty != 0;
+        }
+        const bool ld = a.ldirty[e] != 0;
+        const bool wd = a.wdirty[e] != 0;
+        M4 w;
+        if (pd || ld || wd) {  // :62-64
+            M4 pm;
             if (HAS_BASE) {
-                bp = a.parent[e];
-                pd = a.wdirty[bp] != 0;
+                load_row<16>(a.world, bp, pm.v);
             } else {
-                pd = root_dirty != 0;
-            }
-            const bool ld = a.ldirty[e] != 0;
-            const bool wd = a.wdirty[e] != 0;
-            M4 w;
-            if (pd || ld || wd) {  // :62-64
-                M4 pm;
-                if (HAS_BASE) {
-                    load_row<16>(a.world, bp, pm.v);
-                } else {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) pm.v[q] = a.root[q];
-                }
-                a.wdirty[e] = 1;  // :65
-                if (ld || pd) {   // :67-68
-                    M4 l;
-                    load_row<16>(a.lmat, e, l.v);
-                    w = m4_mul(pm, l);
-                    store_row<16>(a.world, e, w.v);
-                } else {  // :69-72 world-edited entity: re-derive the local matrix
-                    load_row<16>(a.world, e, w.v);
-                    M4 inv;
-                    if (!m4_inverse(pm, inv)) inv = m4_identity();
-                    const M4 l = m4_mul(inv, w);
-                    store_row<16>(const_cast<float*>(a.lmat), e, l.v);
-                }
-            } else {
+                for (int q = 0; q < 16; ++q) pm.v[q] = a.root[q];
+            }
+            a.wdirty[e] = 1;  // :65
+            if (ld || pd) {   // :67-68
+                M4 l;
+                load_row<16>(a.lmat, e, l.v);
+                w = m4_mul(pm, l);
+                store_row<16>(a.world, e, w.v);
+            } else {  // :69-72 world-edited entity: re-derive the local matrix
                 load_row<16>(a.world, e, w.v);
+                M4 inv;
+                if (!m4_inverse(pm, inv)) inv = m4_identity();
+                const M4 l = m4_mul(inv, w);
+                store_row<16>(const_cast<float*>(a.lmat), e, l.v);
             }
-            if (BOUNDS != 0) {
-                float b[6] = {0, 0, 0, 0, 0, 0};
-                uint32_t mesh = 0;
-                if (BOUNDS == 1) load_row<6>(a.bounds, e, b);
-                else mesh = a.mesh_id[e];
-                cull_entity<BOUNDS>(a, w, b, mesh, vmask, bmask);
-            }
+        } else {
+            load_row<16>(a.world, e, w.v);
         }
         if (BOUNDS != 0) {
-            const uint64_t c0 = e64 - (tid & 63u);
-            publish_visible(a, (uint32_t)(e64 >> 6), c0 < a.begin, vmask, bmask);
+            float b[6] = {0, 0, 0, 0, 0, 0};
+            uint32_t mesh = 0;
+            if (BOUNDS == 1) load_row<6>(a.bounds, e, b);
+            else mesh = a.mesh_id[e];
+            cull_entity<BOUNDS>(a, w, b, mesh, vmask, bmask);
         }
     }
+    if (BOUNDS != 0) publish_visible(a, (uint32_t)(e64 >> 6), e64 - (tid & 63u) < a.begin, vmask, bmask);
 }
 
 // ---- stage 3 back end, part 2: prefix sums + expansion into ordered draw lists -----------------------------

@@ -778,15 +778,8 @@ extern "C" int yh_decompose(yh_scene* s, int which, float* const planes[10], uin
 // ------------------------------------------------------------------------------------------------ frame
 template <int BOUNDS>
 static void launch_trs(bool has_base, dim3 grid, hipStream_t st, const FrameArgs& a) {
-    static const char* pf_env = getenv("YH_TUNE_PREFETCH");  // tuning knob: 0 / 1
-    const bool prefetch = pf_env ? (atoi(pf_env) != 0) : false;  // measured: occupancy beats the register double buffer
-    if (has_base) {
-        if (prefetch) hipLaunchKernelGGL((k_frame_trs<BOUNDS, true, true>), grid, dim3(YH_BLOCK), 0, st, a);
-        else hipLaunchKernelGGL((k_frame_trs<BOUNDS, true, false>), grid, dim3(YH_BLOCK), 0, st, a);
-    } else {
-        if (prefetch) hipLaunchKernelGGL((k_frame_trs<BOUNDS, false, true>), grid, dim3(YH_BLOCK), 0, st, a);
-        else hipLaunchKernelGGL((k_frame_trs<BOUNDS, false, false>), grid, dim3(YH_BLOCK), 0, st, a);
-    }
+    if (has_base) hipLaunchKernelGGL((k_frame_trs<BOUNDS, true>), grid, dim3(YH_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((k_frame_trs<BOUNDS, false>), grid, dim3(YH_BLOCK), 0, st, a);
 }
 
 template <int BOUNDS, bool HAS_BASE>
@@ -804,11 +797,11 @@ static void launch_chain(int G, bool has_base, dim3 grid, hipStream_t st, const 
 }
 
 template <int BOUNDS>
-static void launch_mat4(bool has_base, dim3 grid, size_t lds, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
+static void launch_mat4(bool has_base, dim3 grid, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
     if (has_base) {
-        hipLaunchKernelGGL((k_level_mat4<BOUNDS, true>), grid, dim3(YH_BLOCK), lds, st, a, root_dirty);
+        hipLaunchKernelGGL((k_level_mat4<BOUNDS, true>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
     } else {
-        hipLaunchKernelGGL((k_level_mat4<BOUNDS, false>), grid, dim3(YH_BLOCK), lds, st, a, root_dirty);
+        hipLaunchKernelGGL((k_level_mat4<BOUNDS, false>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
     }
 }
 
@@ -855,17 +848,8 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     memcpy(a.root, s->root, sizeof a.root);
     if (cull) memcpy(a.planes, planes, (size_t)n_frusta * 24 * sizeof(float));
     const int bounds = cull ? (int)s->desc.bounds_kind : 0;
-    // slices per workgroup: with more than one slice the next slice's inputs are prefetched while the current one
-    // is computed; small launches keep one slice per workgroup so that the grid fills the chip
-    auto pick_iters = [](uint64_t n_launch) -> uint32_t {
-        static const char* it_env = getenv("YH_TUNE_ITERS");  // tuning knob
-        if (it_env) return (uint32_t)std::min<int>(std::max<int>(atoi(it_env), 1), YH_MAX_ITERS);
-        (void)n_launch;
-        return 1u;  // measured with streaming loads/stores: one slice per workgroup wins at every size
-    };
-    auto lds_bytes = [&](uint32_t) -> size_t { return 0; };
     auto grid_for = [&](const FrameArgs& fa) -> dim3 {
-        return dim3(cdiv((uint64_t)fa.end - (fa.begin & ~63u), (uint64_t)fa.iters * YH_BLOCK));
+        return dim3(cdiv((uint64_t)fa.end - (fa.begin & ~63u), YH_BLOCK));  // chunk-aligned 256-entity tiles
     };
 
     const bool frame_events = s->kernel_timing && s->timing_only < 0 && (s->frames % s->timing_period == 0);
@@ -901,7 +885,6 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
             const bool has_base = g.lo > 0;
             if (int rc = time_begin(gi)) return rc;
             if (g.hi > g.lo) {
-                a.iters = 1;
                 for (uint32_t j = 0; j < YH_MAX_GROUP; ++j)
                     a.lvl_begin[j] = (g.lo + 1 + j <= g.hi) ? s->level_offsets[g.lo + 1 + j] : 0xFFFFFFFFu;
                 const dim3 grid = grid_for(a);
@@ -910,7 +893,6 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
                 else if (bounds == 1) launch_chain<1>(G, has_base, grid, st, a);
                 else launch_chain<2>(G, has_base, grid, st, a);
             } else {
-                a.iters = pick_iters((uint64_t)a.end - a.begin);
                 const dim3 grid = grid_for(a);
                 if (bounds == 0) launch_trs<0>(has_base, grid, st, a);
                 else if (bounds == 1) launch_trs<1>(has_base, grid, st, a);
@@ -927,13 +909,11 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
             a.end = s->level_offsets[k + 1];
             if (a.end == a.begin) continue;
             const bool has_base = k > 0;
-            a.iters = pick_iters((uint64_t)a.end - a.begin);
-            const size_t lds = lds_bytes(a.iters);
             const dim3 grid = grid_for(a);
             if (int rc = time_begin(k)) return rc;
-            if (bounds == 0) launch_mat4<0>(has_base, grid, lds, st, a, s->root_dirty);
-            else if (bounds == 1) launch_mat4<1>(has_base, grid, lds, st, a, s->root_dirty);
-            else launch_mat4<2>(has_base, grid, lds, st, a, s->root_dirty);
+            if (bounds == 0) launch_mat4<0>(has_base, grid, st, a, s->root_dirty);
+            else if (bounds == 1) launch_mat4<1>(has_base, grid, st, a, s->root_dirty);
+            else launch_mat4<2>(has_base, grid, st, a, s->root_dirty);
             HIP_TRY(ctx, hipGetLastError());
             if (int rc = time_end()) return rc;
             ++launches;
@@ -991,8 +971,7 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         x.n_tiles = s->n_tiles;
         x.words = s->tile_words;
         x.id_base = s->desc.id_base;
-        static const char* sc_env = getenv("YH_TUNE_SELFCOUNT");  // tuning knob
-        x.self_count = s->n_tiles <= (sc_env ? (uint32_t)atoi(sc_env) : (uint32_t)YH_SELF_COUNT_TILES);
+        x.self_count = s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES;
         if (int rc = time_begin(YH_MAX_LEVELS - 1)) return rc;
         if (!x.self_count) {
             hipLaunchKernelGGL(k_count, dim3(s->n_tiles, n_frusta), dim3(YH_BLOCK), 0, st, x);
