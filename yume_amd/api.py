@@ -181,9 +181,11 @@ class Scene:
     def frame(self, planes=None, flags=L.YH_FRAME_ALL_DIRTY):
         if planes is None:
             self._ck(L.lib().yh_frame(self._h, None, 0, flags))
+            self._last_frusta = 0
             return
         planes = np.ascontiguousarray(planes, np.float32).reshape(-1, 24)
         self._ck(L.lib().yh_frame(self._h, _ptr(planes), planes.shape[0], flags))
+        self._last_frusta = 0 if flags & L.YH_FRAME_NO_CULL else planes.shape[0]
 
     def counts(self):
         c = np.zeros(L.YH_MAX_FRUSTA, np.uint32)
@@ -314,7 +316,8 @@ class Scene:
 
     # ---- multi-GPU ----
     def allgather_draw_lists(self):
-        out = np.zeros((self.ctx.n_ranks, max(1, self.n_frusta)), np.uint32)
+        """(n_ranks, frusta of the last frame) visible counts; lists via gathered_draw_list()."""
+        out = np.zeros((self.ctx.n_ranks, max(1, getattr(self, "_last_frusta", self.n_frusta))), np.uint32)
         self._ck(L.lib().yh_allgather_draw_lists(self._h, _ptr(out)))
         return out
 

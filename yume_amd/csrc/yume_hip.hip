@@ -434,6 +434,7 @@ extern "C" int yh_upload_hierarchy(yh_scene* s, const uint32_t* parent_index, co
         }
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_scene(s)) return rc;  // frames in flight still read the old hierarchy
     HIP_TRY(ctx, hipMemcpy(s->parent, parent_index, s->n * 4, hipMemcpyHostToDevice));
     s->level_offsets.assign(level_offsets, level_offsets + L + 1);
     s->have_hierarchy = true;

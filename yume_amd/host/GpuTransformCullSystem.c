@@ -220,11 +220,15 @@ static int same_as_last_walk(const GpuTransformCullSystem* s) {
 }
 
 /* ---- rebuild of the slot order ----------------------------------------------------------------------------- */
-static const uint32_t* g_sort_key;
+typedef struct KeyedBatch {
+    uint32_t key;   /* slot of the batch's parent */
+    uint32_t batch; /* index into batches[] = walk order */
+} KeyedBatch;
 static int by_key(const void* a, const void* b) {
-    const uint32_t ia = *(const uint32_t*)a, ib = *(const uint32_t*)b;
-    if (g_sort_key[ia] != g_sort_key[ib]) return g_sort_key[ia] < g_sort_key[ib] ? -1 : 1;
-    return ia < ib ? -1 : (ia > ib); /* stable: walk order among equals */
+    const KeyedBatch* x = (const KeyedBatch*)a;
+    const KeyedBatch* y = (const KeyedBatch*)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->batch < y->batch ? -1 : (x->batch > y->batch); /* stable: walk order among equals */
 }
 
 static int rebuild(GpuTransformCullSystem* s) {
@@ -237,10 +241,11 @@ static int rebuild(GpuTransformCullSystem* s) {
     uint32_t* key = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
     uint32_t* parent_index = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
     uint32_t* stack = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
+    KeyedBatch* keyed = (KeyedBatch*)malloc(sizeof(KeyedBatch) * (nb ? nb : 1));
     uint32_t level_offsets[YH_MAX_LEVELS + 1];
     free(s->order);
     s->order = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
-    if (!parent_batch || !parent_row || !key || !parent_index || !stack || !s->order || map_init(&batch_of, n) != 0) {
+    if (!parent_batch || !parent_row || !key || !parent_index || !stack || !keyed || !s->order || map_init(&batch_of, n) != 0) {
         rc = YH_ERR_OOM;
         goto done;
     }
@@ -293,10 +298,12 @@ static int rebuild(GpuTransformCullSystem* s) {
                 const Batch* pb = &s->batches[parent_batch[b]];
                 key[b] = pb->slot_begin + (parent_row[b] - pb->walk_begin); /* parent's slot: assigned one level up */
             }
-            s->order[placed++] = b;
+            keyed[placed].key = key[b];
+            keyed[placed].batch = b;
+            placed++;
         }
-        g_sort_key = key;
-        qsort(s->order + first, placed - first, sizeof(uint32_t), by_key);
+        qsort(keyed + first, placed - first, sizeof(KeyedBatch), by_key);
+        for (uint32_t i = first; i < placed; ++i) s->order[i] = keyed[i].batch;
         for (uint32_t i = first; i < placed; ++i) {
             Batch* b = &s->batches[s->order[i]];
             b->slot_begin = slot;
@@ -391,6 +398,7 @@ done:
     free(key);
     free(parent_index);
     free(stack);
+    free(keyed);
     if (rc != YH_OK) s->cached_n = 0, s->cached_batches = 0;
     return rc;
 }
