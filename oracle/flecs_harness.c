@@ -29,13 +29,15 @@
  * out.bin:   per frame: world rows n x 68 B, local rows n x 68 B (all zero for deleted entities), u64 batches,
  *            u64 rows_seen, u32 up_fields_shared; GPU build + YFH2: then per frustum u32 count, u32 entity_index[count]
  *            (GPU build: batches = slot-order rebuilds so far, rows_seen = entities in the device scene), then
- *            u64 rows_up, u64 rows_down = 68-byte rows that crossed PCIe in the frame.  GPU build, env YFH_PLAIN=1:
- *            whole columns both ways every frame instead of the incremental mode.
+ *            u64 rows_up, u64 rows_down = 68-byte rows that crossed PCIe in the frame, u64 walks, u64 walks_skipped
+ *            (query iterations done / frames that reused the last one).  GPU build, env YFH_PLAIN=1: whole columns both
+ *            ways every frame instead of the incremental mode; YFH_ALWAYS_WALK=1: iterate the query every frame.
  */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "flecs.h"
 #include "yume_oracle.h"
@@ -190,6 +192,7 @@ int main(int argc, char** argv) {
         GpuTransformCullSystem_setFrusta(gpu, planes, n_frusta);
     }
     if (getenv("YFH_PLAIN")) GpuTransformCullSystem_setIncremental(gpu, 0);
+    if (getenv("YFH_ALWAYS_WALK")) GpuTransformCullSystem_setSkipWalks(gpu, 0);
     ecs_entity_t* vis = malloc(sizeof(ecs_entity_t) * n);
     uint32_t* vis_idx = malloc(sizeof(uint32_t) * n);
 #else
@@ -226,6 +229,8 @@ int main(int argc, char** argv) {
             ecs_modified_id(w, target, comp); /* -> onSet -> dirty */
         }
         g_batches = g_rows = 0;
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
         /* PostUpdate: TransformSyncSystem, then its two dependents (ecs.zig:277-293) */
 #ifdef USE_GPU_SYSTEM
         ecs_run(w, gsys, 0.016f, NULL);
@@ -241,6 +246,9 @@ int main(int argc, char** argv) {
         ecs_run(w, post_w, 0.016f, NULL);
         ecs_run(w, post_l, 0.016f, NULL);
 #endif
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (getenv("YFH_TIMES")) /* wall time of the frame's systems, edits excluded */
+            fprintf(stderr, "frame %u: %.3f ms, %u edits\n", f, (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, n_edits);
         for (int comp = 0; comp < 2; ++comp) {
             for (uint32_t e = 0; e < n; ++e) {
                 memset(&rows[e], 0, sizeof rows[e]);
@@ -273,6 +281,9 @@ int main(int argc, char** argv) {
         uint64_t traffic[2];
         GpuTransformCullSystem_lastTraffic(gpu, &traffic[0], &traffic[1]);
         fwrite(traffic, 8, 2, fout);
+        uint64_t walk_stats[2];
+        GpuTransformCullSystem_walkStats(gpu, &walk_stats[0], &walk_stats[1]);
+        fwrite(walk_stats, 8, 2, fout);
 #endif
     }
 #ifdef USE_GPU_SYSTEM

@@ -57,8 +57,8 @@ def read_out(path, n, n_frames, n_frusta, T68, gpu=False):
             vis.append(np.frombuffer(raw, np.uint32, c, pos + 4).copy())
             pos += 4 + 4 * c
         if gpu:
-            vis.append(struct.unpack_from("<QQ", raw, pos))  # last element: (rows up, rows down)
-            pos += 16
+            vis.append(struct.unpack_from("<QQQQ", raw, pos))  # last element: (rows up, rows down, walks, skipped)
+            pos += 32
         res.append((w, l, a, b, vis))
     assert pos == len(raw)
     return res
@@ -70,9 +70,10 @@ def reparent_arg(index):
     return m
 
 
-@pytest.mark.parametrize("plain", [False, True], ids=["incremental", "whole-columns"])
+@pytest.mark.parametrize("plain,always_walk", [(False, False), (True, False), (False, True)],
+                         ids=["incremental", "whole-columns", "incremental-always-walk"])
 @pytest.mark.parametrize("n,levels", [(10_000, 1), (4096, 8), (50_000, 6)])
-def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, levels, plain):
+def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, levels, plain, always_walk):
     rng = np.random.default_rng(n + levels)
     lo = oracle.synth_level_offsets(n, levels)
     par = oracle.synth_parents(lo)
@@ -106,8 +107,11 @@ def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, le
     subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
     env = dict(os.environ)
     env.pop("YFH_PLAIN", None)
+    env.pop("YFH_ALWAYS_WALK", None)
     if plain:
         env["YFH_PLAIN"] = "1"
+    if always_walk:
+        env["YFH_ALWAYS_WALK"] = "1"
     subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
     cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
     gpu = read_out(out_g, n, len(frames), planes.shape[0], oracle.T68, gpu=True)
@@ -127,7 +131,12 @@ def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, le
         structural = any(kind in (2, 3) for _e, kind, _m in frames[fi])
         assert rebuilds == rebuilds_before + (1 if (fi == 0 or structural) else 0), f"frame {fi}: rebuild count"
         rebuilds_before = rebuilds
-        up, down = vis[-1]
+        up, down, walks, skipped = vis[-1]
+        assert walks + skipped == fi + 1
+        if always_walk:
+            assert skipped == 0
+        else:  # the query is iterated on the first frame and on the frames after a structural change, only
+            assert walks == rebuilds, f"frame {fi}: {walks} walks for {rebuilds} rebuilds"
         if plain:
             assert up == down == 2 * g_rows, f"frame {fi}: whole columns travel in plain mode"
         elif not (fi == 0 or structural):

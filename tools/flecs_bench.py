@@ -1,0 +1,37 @@
+"""End-to-end frame time inside the REAL flecs (oracle/_ref harnesses): the reference's CPU systems against the GPU
+system, whole-column and incremental modes.  usage: python tools/flecs_bench.py [n] [levels]
+Frames: 0 everything dirty (first frame), 1 nothing dirty, 2 1 % local edits, 3 nothing dirty, 4 root moved."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as oracle  # noqa: E402  (measurement script: the oracle generates the scene)
+from tests.test_gpu_flecs_system import CPU, GPU, write_scene  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+levels = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+rng = np.random.default_rng(1)
+lo = oracle.synth_level_offsets(n, levels)
+par = oracle.synth_parents(lo)
+local = oracle.compose_batch(oracle.synth_trs(n, int(lo[1])))
+bounds = oracle.synth_aabb(n)
+planes = oracle.main_camera_planes().reshape(1, 24)
+m = oracle.compose([1, 2, 3], [0, 0, 0, 1], [1, 1, 1])
+edits = [(int(e), 0, m) for e in np.unique(rng.integers(0, n, n // 100))]
+frames = [[], [], edits, [], [(-1, 1, oracle.compose([1, 2, 3], [0, 0.7071068, 0, 0.7071068], [2, 2, 2]))]]
+with tempfile.TemporaryDirectory() as d:
+    scene = os.path.join(d, "scene.bin")
+    write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
+    for label, binary, env in (("CPU systems (reference rule, real flecs)", CPU, {}),
+                               ("GPU system, whole columns", GPU, {"YFH_PLAIN": "1"}),
+                               ("GPU system, incremental", GPU, {})):
+        e = dict(os.environ, YFH_TIMES="1", **env)
+        e.pop("YFH_PLAIN", None) if "YFH_PLAIN" not in env else None
+        r = subprocess.run([binary, scene, os.path.join(d, "out.bin")], env=e, capture_output=True, text=True, timeout=1200)
+        times = [line.split(": ")[1].split(" ms")[0] for line in r.stderr.splitlines() if line.startswith("frame ")]
+        print(f"{label:45s} n={n} L={levels}  ms per frame: " + "  ".join(times), flush=True)
