@@ -129,6 +129,57 @@ def cpu_baseline(args, wl, n, lo, parent, planes, seconds):
     return out
 
 
+def cpu_baseline_flecs(wl, lo_levels):
+    """The same rule driven by the REAL flecs 4.0.4 the reference vendors (oracle/_ref/flecs_harness, compiled from the
+    reference's flecs sources in place; the per-row arithmetic is the oracle's restatement: Zig cannot be built here).
+    Transform systems only (the reference has no cull), every LocalTransform dirty in frame 0, on a bounded sample."""
+    import struct
+    import subprocess
+    import tempfile
+
+    from oracle import pyoracle as oracle
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(here, "oracle", "_ref", "flecs_harness")
+    if not os.path.exists(exe):
+        return None
+    n_s = 200_000
+    lo = oracle.synth_level_offsets(n_s, lo_levels)
+    par = oracle.synth_parents(lo)
+    local = oracle.compose_batch(oracle.synth_trs(n_s, int(lo[1])))
+    root = oracle.identity68()["m"][0]
+    edit = np.asarray(oracle.compose([1, 2, 3], [0, 0, 0, 1], [1, 1, 1]), np.float32)
+    n_frames = 6  # frame 0: everything dirty (creation); then the root is re-set each frame: every row recomputes
+    with tempfile.TemporaryDirectory() as d:
+        scene = os.path.join(d, "scene.bin")
+        with open(scene, "wb") as f:
+            f.write(b"YFH1")
+            f.write(struct.pack("<III", n_s, lo_levels, n_frames))
+            f.write(lo.astype(np.uint32).tobytes())
+            f.write(par.astype(np.uint32).tobytes())
+            f.write(np.ascontiguousarray(local["m"], np.float32).tobytes())
+            f.write(np.ascontiguousarray(root, np.float32).tobytes())
+            for k in range(n_frames):
+                if k == 0:
+                    f.write(struct.pack("<I", 0))
+                else:
+                    f.write(struct.pack("<III", 1, 0xFFFFFFFF, 1))
+                    f.write(edit.tobytes())
+        try:
+            r = subprocess.run([exe, scene, os.path.join(d, "out.bin")], env=dict(os.environ, YFH_TIMES="1"),
+                               capture_output=True, text=True, timeout=300)
+        except Exception:  # noqa: BLE001
+            return None
+    ms = [float(line.split(": ")[1].split(" ms")[0]) for line in r.stderr.splitlines() if line.startswith("frame ")]
+    if len(ms) < 2:
+        return None
+    med = float(np.median(ms[1:]))
+    return {"value": round(n_s / med / 1e3, 3), "unit": "Mentities/s", "cores": 1, "kind": "port",
+            "ns_per_entity": round(med * 1e6 / n_s, 2),
+            "sample": f"{len(ms) - 1} all-dirty frames of a {n_s}-entity {lo_levels}-level scene inside the reference's vendored "
+                      f"flecs 4.0.4 (TransformSyncSystem rule + both PostTransform sweeps, no cull; median)"}
+
+
 def kernel_symbol(levels_in_group, bounds, has_base):
     """Name rocprofv3 reports for the launch of a level group (yume_hip.hip launch_trs / launch_chain)."""
     hb = "true" if has_base else "false"
@@ -352,6 +403,7 @@ def main():
     }
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
         result.update(cpu_baseline(args, wl, n, lo, parent, planes, args.cpu_seconds))
+        result["cpu_baseline_in_flecs"] = cpu_baseline_flecs(wl, wl["levels"])
     elif rank == 0:
         result["cpu_baseline"] = None
 
