@@ -634,12 +634,16 @@ static void run(ecs_iter_t* it) {
             return;
         }
         const Batch* b = NULL;
-        for (uint64_t i = 0; i < m; ++i) { /* ascending slots: the batch changes rarely */
+        for (uint64_t i = 0; i < m;) { /* ascending slots: runs of consecutive slots inside a batch go in one copy */
             const uint32_t slot = s->slot_buf[i];
             if (!b || slot < b->slot_begin || slot >= b->slot_begin + b->count) b = batch_of_slot(s, slot);
-            const size_t r = (size_t)(slot - b->slot_begin) * ROW;
-            memcpy((uint8_t*)b->world_col + r, s->stage_w + i * ROW, ROW);
-            memcpy((uint8_t*)b->local_col + r, s->stage_l + i * ROW, ROW);
+            const uint32_t batch_end = b->slot_begin + b->count;
+            uint64_t j = i + 1;
+            while (j < m && s->slot_buf[j] == slot + (uint32_t)(j - i) && s->slot_buf[j] < batch_end) ++j;
+            const size_t r = (size_t)(slot - b->slot_begin) * ROW, bytes = (size_t)(j - i) * ROW;
+            memcpy((uint8_t*)b->world_col + r, s->stage_w + i * ROW, bytes);
+            memcpy((uint8_t*)b->local_col + r, s->stage_l + i * ROW, bytes);
+            i = j;
         }
         s->last_down_rows = 2 * m;
     }
