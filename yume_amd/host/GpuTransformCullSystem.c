@@ -454,15 +454,24 @@ static void restore_slots(GpuTransformCullSystem* s) {
     }
 }
 
+/* column pointers of a batch restored without a walk */
+static Batch* batch_cols(Batch* b) {
+    if (!b->world_col) {
+        b->world_col = ecs_table_get_column(b->table, b->col_w, 0);
+        b->local_col = ecs_table_get_column(b->table, b->col_l, 0);
+    }
+    return b;
+}
+
 /* batch holding a slot: binary search over the batches in slot order */
-static const Batch* batch_of_slot(const GpuTransformCullSystem* s, uint32_t slot) {
+static const Batch* batch_of_slot(GpuTransformCullSystem* s, uint32_t slot) {
     uint32_t lo = 0, hi = s->n_batches - 1;
     while (lo < hi) {
         const uint32_t mid = (lo + hi + 1) / 2;
         if (s->batches[s->order[mid]].slot_begin <= slot) lo = mid;
         else hi = mid - 1;
     }
-    return &s->batches[s->order[lo]];
+    return batch_cols(&s->batches[s->order[lo]]);
 }
 
 /* OnSet observers: the same events that run the components' onSet hooks */
@@ -510,8 +519,8 @@ static int restore_walk(GpuTransformCullSystem* s, const ecs_iter_t* it) {
         bt->table = s->cached_tables[b];
         bt->col_w = s->cached_cols[2 * b];
         bt->col_l = s->cached_cols[2 * b + 1];
-        bt->world_col = ecs_table_get_column(bt->table, bt->col_w, 0);
-        bt->local_col = ecs_table_get_column(bt->table, bt->col_l, 0);
+        bt->world_col = NULL; /* fetched on first use (batch_cols): a frame in which nothing moved touches no column */
+        bt->local_col = NULL;
         bt->up_row = NULL;
         bt->src = s->cached_src[b];
         bt->count = s->cached_counts[b];
@@ -574,7 +583,7 @@ static void run(ecs_iter_t* it) {
     if (!s->incremental || rebuilt) {
         /* whole columns up; in plain mode whole columns down again */
         for (uint32_t i = 0; i < s->n_batches; ++i) {
-            const Batch* b = &s->batches[i];
+            const Batch* b = batch_cols(&s->batches[i]);
             memcpy(s->stage_w + (size_t)b->slot_begin * ROW, b->world_col, (size_t)b->count * ROW);
             memcpy(s->stage_l + (size_t)b->slot_begin * ROW, b->local_col, (size_t)b->count * ROW);
         }
@@ -621,7 +630,7 @@ static void run(ecs_iter_t* it) {
             return;
         }
         for (uint32_t i = 0; i < s->n_batches; ++i) {
-            const Batch* b = &s->batches[i];
+            const Batch* b = batch_cols(&s->batches[i]);
             memcpy(b->world_col, s->stage_w + (size_t)b->slot_begin * ROW, (size_t)b->count * ROW);
             memcpy(b->local_col, s->stage_l + (size_t)b->slot_begin * ROW, (size_t)b->count * ROW);
         }
