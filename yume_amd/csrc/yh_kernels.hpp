@@ -290,6 +290,95 @@ __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, cons
     if (BOUNDS != 0) publish_visible(a, (uint32_t)(e64 >> 6), e64 - (tid & 63u) < a.begin, vmask, bmask);
 }
 
+// The same rule for a GROUP of consecutive levels in one launch (the Mat4 twin of k_frame_chain).  An entity walks up
+// to the group's first level, takes the stored world matrix AND this frame's dirty flag of the base parent (written by
+// an earlier launch, or the scene root's), and replays the rule down its chain in registers: an ancestor that is
+// dirty through its local or its parent contributes parent * local (forward branch), any other ancestor contributes
+// its stored world matrix (clean, or edited in world space: the reverse branch leaves the world matrix alone), and
+// "dirty" propagates exactly as WorldTransform.dirty does level by level.  The entity's own row then goes through
+// the literal three branches.  Flags read from an ancestor may already have been rewritten by that ancestor's own
+// lane in this launch: the only rewrite is wdirty 0 -> 1 on a row the rule found dirty anyway, so the replay's
+// outcome is the same; world[a] is only rewritten in the forward branch, where the replay does not read it; lmat[a]
+// only in the reverse branch, where the replay does not read it either.
+template <int G, int BOUNDS, bool HAS_BASE>
+__global__ __launch_bounds__(YH_BLOCK) void k_chain_mat4(const FrameArgs a, const uint32_t root_dirty) {
+    const uint32_t tid = threadIdx.x;
+    const uint64_t e64 = (uint64_t)(a.begin & ~63u) + (uint64_t)blockIdx.x * YH_BLOCK + tid;
+    if (e64 - (tid & 63u) >= a.end) return;  // wave-uniform
+    const bool valid = e64 >= a.begin && e64 < a.end;
+    const uint32_t e = (uint32_t)e64;
+    uint32_t vmask = 0, bmask = 0;
+    if (valid) {
+        int d = 0;
+#pragma unroll
+        for (int j = 0; j < G - 1; ++j) d += (e >= a.lvl_begin[j]) ? 1 : 0;
+        uint32_t chain[G];
+        uint32_t p = e, pp = 0;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            chain[j] = p;
+            if (j < d || (HAS_BASE && j == d)) {
+                pp = a.parent[p];
+                if (j < d) p = pp;
+            }
+        }
+        M4 pm;
+        bool pd;
+        if (HAS_BASE) {  // pp = parent of chain[d]
+            load_row<16>(a.world, pp, pm.v);
+            pd = a.wdirty[pp] != 0;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) pm.v[q] = a.root[q];
+            pd = root_dirty != 0;
+        }
+#pragma unroll
+        for (int j = G - 1; j >= 1; --j) {
+            if (j <= d) {
+                const uint32_t anc = chain[j];
+                const bool ld = a.ldirty[anc] != 0;
+                const bool wd = a.wdirty[anc] != 0;
+                if (ld || pd) {
+                    M4 l;
+                    load_row<16>(a.lmat, anc, l.v);
+                    pm = m4_mul(pm, l);
+                } else {
+                    load_row<16>(a.world, anc, pm.v);
+                }
+                pd = pd || ld || wd;
+            }
+        }
+        const bool ld = a.ldirty[e] != 0;
+        const bool wd = a.wdirty[e] != 0;
+        M4 w;
+        if (pd || ld || wd) {  // TransformSyncSystem.zig:62-64
+            a.wdirty[e] = 1;   // :65
+            if (ld || pd) {    // :67-68
+                M4 l;
+                load_row<16>(a.lmat, e, l.v);
+                w = m4_mul(pm, l);
+                store_row<16>(a.world, e, w.v);
+            } else {  // :69-72
+                load_row<16>(a.world, e, w.v);
+                M4 inv;
+                if (!m4_inverse(pm, inv)) inv = m4_identity();
+                const M4 l = m4_mul(inv, w);
+                store_row<16>(const_cast<float*>(a.lmat), e, l.v);
+            }
+        } else {
+            load_row<16>(a.world, e, w.v);
+        }
+        if (BOUNDS != 0) {
+            float b[6] = {0, 0, 0, 0, 0, 0};
+            uint32_t mesh = 0;
+            if (BOUNDS == 1) load_row<6>(a.bounds, e, b);
+            else mesh = a.mesh_id[e];
+            cull_entity<BOUNDS>(a, w, b, mesh, vmask, bmask);
+        }
+    }
+    if (BOUNDS != 0) publish_visible(a, (uint32_t)(e64 >> 6), e64 - (tid & 63u) < a.begin, vmask, bmask);
+}
+
 // ---- stage 3 back end, part 2: prefix sums + expansion into ordered draw lists -----------------------------
 // An expand tile is `words` visibility words (64 = 4096 entities, or 256 for scenes beyond 16M entities).
 // k_count reduces every tile to its visible count; k_expand gives one workgroup to each (tile, frustum): its base

@@ -353,19 +353,20 @@ static int plan_groups(yh_scene* s) {
         s->groups = s->explicit_plan;
         return YH_OK;
     }
-    const bool trs = s->desc.local_kind == YH_LOCAL_TRS;
     auto span = [&](uint32_t lo, uint32_t hi) -> uint64_t { return (uint64_t)s->level_offsets[hi + 1] - s->level_offsets[lo]; };
     const uint64_t resident = 320 * 1024;
     uint32_t lo = 0;
     while (lo < L) {
         uint32_t hi = lo;
-        if (!trs || s->max_group_levels == 1) {
+        if (s->max_group_levels == 1) {
             // one level per launch
         } else if (s->max_group_levels) {
             hi = std::min<uint32_t>(L - 1, lo + std::min<uint32_t>(s->max_group_levels, YH_MAX_GROUP) - 1);
         } else {
             while (hi + 1 < L && hi + 1 - lo < YH_MAX_GROUP && span(lo, hi + 1) <= resident) ++hi;
-            if (hi == lo && span(lo, lo) > resident / 4) {  // a large level: groups of three, the remainder first
+            if (hi == lo && span(lo, lo) > resident / 4 && s->desc.local_kind == YH_LOCAL_TRS) {  // a large level: groups of three, the remainder first
+                // (Mat4 scenes keep large levels one per launch: replaying ancestors' flags and rows costs more than the
+                // launch boundary there, measured 314 vs 218 us on a clean 12.5M-entity frame)
                 uint32_t big_end = lo;  // the run of levels that no longer fit the residency rule
                 while (big_end + 1 < L) ++big_end;
                 const uint32_t run = big_end - lo + 1;
@@ -394,7 +395,6 @@ extern "C" int yh_scene_set_grouping(yh_scene* s, uint32_t max_group_levels) {
 extern "C" int yh_scene_set_plan(yh_scene* s, uint32_t n_groups, const uint32_t* last_level) {
     if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_scene_set_plan: scene is NULL");
     yh_ctx* ctx = s->ctx;
-    ARG_TRY(ctx, s->desc.local_kind == YH_LOCAL_TRS, "yh_scene_set_plan: Mat4 scenes run one level per launch");
     std::vector<LevelGroup> plan;
     if (n_groups) {
         ARG_TRY(ctx, last_level, "yh_scene_set_plan: last_level is NULL");
@@ -797,6 +797,20 @@ static void launch_chain(int G, bool has_base, dim3 grid, hipStream_t st, const 
     else launch_chain_g<BOUNDS, false>(G, grid, st, a);
 }
 
+template <int BOUNDS, bool HAS_BASE>
+static void launch_chain_mat4_g(int G, dim3 grid, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
+    if (G <= 2) hipLaunchKernelGGL((k_chain_mat4<2, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
+    else if (G <= 3) hipLaunchKernelGGL((k_chain_mat4<3, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
+    else if (G <= 4) hipLaunchKernelGGL((k_chain_mat4<4, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
+    else if (G <= 6) hipLaunchKernelGGL((k_chain_mat4<6, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
+    else hipLaunchKernelGGL((k_chain_mat4<8, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
+}
+template <int BOUNDS>
+static void launch_chain_mat4(int G, bool has_base, dim3 grid, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
+    if (has_base) launch_chain_mat4_g<BOUNDS, true>(G, grid, st, a, root_dirty);
+    else launch_chain_mat4_g<BOUNDS, false>(G, grid, st, a, root_dirty);
+}
+
 template <int BOUNDS>
 static void launch_mat4(bool has_base, dim3 grid, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
     if (has_base) {
@@ -905,16 +919,26 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         }
     } else {
         if (flags & YH_FRAME_ALL_DIRTY) HIP_TRY(ctx, hipMemsetAsync(s->ldirty, 1, s->stride, st));
-        for (uint32_t k = 0; k < s->desc.n_levels; ++k) {
-            a.begin = s->level_offsets[k];
-            a.end = s->level_offsets[k + 1];
+        for (uint32_t gi = 0; gi < s->groups.size(); ++gi) {
+            const LevelGroup g = s->groups[gi];
+            a.begin = s->level_offsets[g.lo];
+            a.end = s->level_offsets[g.hi + 1];
             if (a.end == a.begin) continue;
-            const bool has_base = k > 0;
+            const bool has_base = g.lo > 0;
             const dim3 grid = grid_for(a);
-            if (int rc = time_begin(k)) return rc;
-            if (bounds == 0) launch_mat4<0>(has_base, grid, st, a, s->root_dirty);
-            else if (bounds == 1) launch_mat4<1>(has_base, grid, st, a, s->root_dirty);
-            else launch_mat4<2>(has_base, grid, st, a, s->root_dirty);
+            if (int rc = time_begin(gi)) return rc;
+            if (g.hi > g.lo) {
+                for (uint32_t j = 0; j < YH_MAX_GROUP; ++j)
+                    a.lvl_begin[j] = (g.lo + 1 + j <= g.hi) ? s->level_offsets[g.lo + 1 + j] : 0xFFFFFFFFu;
+                const int G = (int)(g.hi - g.lo + 1);
+                if (bounds == 0) launch_chain_mat4<0>(G, has_base, grid, st, a, s->root_dirty);
+                else if (bounds == 1) launch_chain_mat4<1>(G, has_base, grid, st, a, s->root_dirty);
+                else launch_chain_mat4<2>(G, has_base, grid, st, a, s->root_dirty);
+            } else {
+                if (bounds == 0) launch_mat4<0>(has_base, grid, st, a, s->root_dirty);
+                else if (bounds == 1) launch_mat4<1>(has_base, grid, st, a, s->root_dirty);
+                else launch_mat4<2>(has_base, grid, st, a, s->root_dirty);
+            }
             HIP_TRY(ctx, hipGetLastError());
             if (int rc = time_end()) return rc;
             ++launches;
@@ -1129,15 +1153,6 @@ extern "C" int yh_scene_set_kernel_timing(yh_scene* s, int enable) {
 extern "C" int yh_scene_get_groups(yh_scene* s, uint32_t* quads, uint32_t cap, uint32_t* n_groups) {
     if (!s || !n_groups) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_scene_get_groups: NULL argument");
     if (!s->have_hierarchy) return fail(s->ctx, YH_ERR_STATE, "yh_scene_get_groups: no hierarchy");
-    if (s->desc.local_kind == YH_LOCAL_MAT4) {
-        *n_groups = s->desc.n_levels;
-        for (uint32_t k = 0; k < s->desc.n_levels && k < cap && quads; ++k) {
-            quads[4 * k] = quads[4 * k + 1] = k;
-            quads[4 * k + 2] = s->level_offsets[k];
-            quads[4 * k + 3] = s->level_offsets[k + 1];
-        }
-        return YH_OK;
-    }
     *n_groups = (uint32_t)s->groups.size();
     for (uint32_t i = 0; i < s->groups.size() && i < cap && quads; ++i) {
         quads[4 * i] = s->groups[i].lo;
