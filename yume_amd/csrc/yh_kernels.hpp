@@ -37,6 +37,8 @@ struct FrameArgs {
     uint8_t* wdirty;
     uint32_t* bcount;    // [YH_K_MAX_FRUSTA] boundary-case counters of this frame
     uint64_t* vismask;   // [frustum][n_chunks] one visibility bit per entity (wave ballots)
+    uint8_t* viscnt;     // [frustum][cnt_stride] popcount of each visibility word (read by k_expand of small scenes)
+    uint32_t cnt_stride; // n_chunks rounded up to 16 (rows are read as uint4)
     uint32_t n_chunks;
     uint32_t begin, end;               // entity range of this launch (levels lo..hi)
     uint32_t lvl_begin[YH_MAX_GROUP];  // chain kernel: first slot of levels lo+1, lo+2, ... (0xFFFFFFFF when absent)
@@ -94,7 +96,9 @@ __device__ __forceinline__ void publish_visible(const FrameArgs& a, uint32_t chu
         const uint64_t bm = __ballot((bmask >> f) & 1u);
         if (lane == 0) {
             uint64_t* w = &a.vismask[(uint64_t)f * a.n_chunks + chunk];
-            *w = merge_with_previous_launch ? (*w | m) : m;
+            const uint64_t word = merge_with_previous_launch ? (*w | m) : m;
+            *w = word;
+            a.viscnt[(uint64_t)f * a.cnt_stride + chunk] = (uint8_t)__popcll(word);
             if (bm) atomicAdd(&a.bcount[f], (uint32_t)__popcll(bm));
         }
     }
@@ -385,13 +389,16 @@ __global__ __launch_bounds__(YH_BLOCK) void k_chain_mat4(const FrameArgs a, cons
 // is the sum of the tile counts before it (read redundantly: a few thousand L2-resident words, cheaper than a
 // dependent scan launch), the tile's words are prefix-summed through LDS and the 4 waves expand them
 // round-robin, one word per step: lane l emits entity chunk*64+l at rank mbcnt(word).  Ascending entity order,
-// coalesced stores, no atomics.  Scenes of at most YH_SELF_COUNT_TILES tiles skip k_count: every workgroup
-// popcounts the words before its tile itself.
+// coalesced stores, no atomics.  Scenes of at most YH_SELF_COUNT_TILES tiles (2M entities) skip k_count: the frame
+// kernels store each word's popcount as a byte next to it, and every expand workgroup adds up the bytes before its
+// tile itself (16 per load, v_dot4: at most 32 KiB of L2-resident bytes) — one dependent launch less per frame.
 #define YH_EXPAND_WORDS_MAX 256
-#define YH_SELF_COUNT_TILES 8
+#define YH_SELF_COUNT_TILES 512
 
 struct ExpandArgs {
     const uint64_t* vismask;
+    const uint8_t* viscnt;  // [frustum][cnt_stride] popcounts of the words, written with them
+    uint32_t cnt_stride;
     uint32_t* tilecnt;      // [frustum][n_tiles]
     uint32_t* counts;       // device totals [frustum] (input of the RCCL all-gather)
     uint32_t* bcount_cur;   // boundary counters accumulated by this frame's launches
@@ -435,8 +442,15 @@ __global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) {
     const uint32_t pc = (uint32_t)__popcll(m);
     // base = visible entities in the tiles before this one
     uint32_t part = 0;
-    if (x.self_count) {
-        for (uint32_t i = tid; i < c0; i += YH_BLOCK) part += (uint32_t)__popcll(masks[i]);
+    if (x.self_count) {  // 16 byte-counts per load; c0 is a multiple of 64
+        const uint4* __restrict__ c16 = reinterpret_cast<const uint4*>(x.viscnt + (uint64_t)f * x.cnt_stride);
+        for (uint32_t i = tid; i < c0 / 16; i += YH_BLOCK) {
+            const uint4 v = c16[i];
+            part = __builtin_amdgcn_udot4(v.x, 0x01010101u, part, false);
+            part = __builtin_amdgcn_udot4(v.y, 0x01010101u, part, false);
+            part = __builtin_amdgcn_udot4(v.z, 0x01010101u, part, false);
+            part = __builtin_amdgcn_udot4(v.w, 0x01010101u, part, false);
+        }
     } else {
         const uint32_t* __restrict__ cnt = x.tilecnt + (uint64_t)f * x.n_tiles;
         for (uint32_t i = tid; i < t; i += YH_BLOCK) part += cnt[i];
@@ -483,12 +497,15 @@ __global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) {
 // as the chunk's word of the change mask, then clears both flags.  k_count / k_expand turn the mask into the
 // ascending list of changed slots, exactly as they do for a frustum.
 __global__ __launch_bounds__(YH_BLOCK) void k_sweep_dirty(uint8_t* __restrict__ ld, uint8_t* __restrict__ wd, uint32_t n,
-                                                          uint64_t* __restrict__ words) {
+                                                          uint64_t* __restrict__ words, uint8_t* __restrict__ counts) {
     const uint64_t e = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;  // the grid covers whole chunks
     const bool in = e < n;
     const bool changed = in && ((ld[e] | wd[e]) != 0);
     const uint64_t m = __ballot(changed);
-    if ((threadIdx.x & 63u) == 0) words[e >> 6] = m;
+    if ((threadIdx.x & 63u) == 0 && e < (((uint64_t)n + 63u) & ~63ull)) {  // the last workgroup may reach past the last chunk
+        words[e >> 6] = m;
+        counts[e >> 6] = (uint8_t)__popcll(m);
+    }
     if (in) {
         ld[e] = 0;
         wd[e] = 0;

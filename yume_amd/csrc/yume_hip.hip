@@ -57,6 +57,9 @@ struct yh_scene {
     uint32_t* counts = nullptr;       // device: 8 visible + 2 x 8 boundary totals, then tile counts, then visibility words
     uint32_t* tilecnt = nullptr;      // inside the counts allocation: [n_frusta][n_tiles]
     uint64_t* vismask = nullptr;      // inside the counts allocation: [n_frusta][n_chunks]
+    uint8_t* viscnt = nullptr;        // inside the counts allocation: [n_frusta][cnt_stride] popcounts of the words
+    uint32_t cnt_stride = 0;          // n_chunks rounded up to 16
+    uint8_t* chg_cnt = nullptr;       // the same for the change mask
     uint64_t vis_bytes = 0;           // bytes of the counts allocation (zeroed once at creation)
     uint32_t n_chunks = 0, n_tiles = 0, tile_words = 64;
     uint32_t* h_counts = nullptr;     // host-mapped: written by k_expand ([f] totals, [8+f] boundary counts)
@@ -278,7 +281,7 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
         alloc((void**)&s->mesh_id, S * 4);
     }
     for (uint32_t f = 0; f < d->n_frusta; ++f) alloc((void**)&s->draw[f], s->draw_cap * 4);
-    // stage-3 buffers: one allocation = 32 total words | tile counts | visibility words (8-byte aligned); zeroed once
+    // stage-3 buffers: one allocation = 32 total words | tile counts | visibility words | their popcounts; zeroed once
     // here, never per frame (tile counts and visibility words are fully rewritten, boundary counters alternate)
     s->n_chunks = (uint32_t)(S / YH_CHUNK);
     // expand tiles: 64 words (4096 entities) keep small scenes parallel; 256 words beyond 8M entities (measured)
@@ -286,11 +289,14 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
     s->n_tiles = (s->n_chunks + s->tile_words - 1) / s->tile_words;
     const uint64_t F_alloc = d->n_frusta ? d->n_frusta : 1;
     const uint64_t tile_words = (F_alloc * s->n_tiles + 1) & ~1ull;
-    s->vis_bytes = (4 * YH_MAX_FRUSTA + tile_words) * 4 + F_alloc * s->n_chunks * 8;
+    s->cnt_stride = (s->n_chunks + 15u) & ~15u;
+    s->vis_bytes = (4 * YH_MAX_FRUSTA + tile_words) * 4 + F_alloc * s->n_chunks * 8 + F_alloc * s->cnt_stride + 16;
     alloc((void**)&s->counts, s->vis_bytes);
     if (e == hipSuccess) {
         s->tilecnt = s->counts + 4 * YH_MAX_FRUSTA;  // [0,8) totals, [8,16) and [16,24) boundary counters (two parities)
         s->vismask = (uint64_t*)(s->tilecnt + tile_words);
+        // byte popcounts of the words, rows of cnt_stride bytes read 16 at a time: 16-byte aligned start
+        s->viscnt = (uint8_t*)(((uintptr_t)(s->vismask + F_alloc * s->n_chunks) + 15) & ~(uintptr_t)15);
     }
     if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counts, 2 * YH_MAX_FRUSTA * 4, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&s->h_counts_dev, s->h_counts, 0);
@@ -667,11 +673,12 @@ extern "C" int yh_scene_track_changes(yh_scene* s, int enable) {
     if (int rc = sync_scene(s)) return rc;
     if (enable && !s->chg) {
         const uint64_t tile_words = ((uint64_t)s->n_tiles + 1) & ~1ull;
-        const uint64_t bytes = (32 + tile_words) * 4 + (uint64_t)s->n_chunks * 8;
+        const uint64_t bytes = (32 + tile_words) * 4 + (uint64_t)s->n_chunks * 8 + s->cnt_stride + 16;
         HIP_TRY(ctx, hipMalloc((void**)&s->chg, bytes));
         HIP_TRY(ctx, hipMemset(s->chg, 0, bytes));
         s->chg_tilecnt = s->chg + 32;
         s->chg_words = (uint64_t*)(s->chg_tilecnt + tile_words);
+        s->chg_cnt = (uint8_t*)(((uintptr_t)(s->chg_words + s->n_chunks) + 15) & ~(uintptr_t)15);
         HIP_TRY(ctx, hipMalloc((void**)&s->chg_list, s->stride * 4));
         HIP_TRY(ctx, hipHostMalloc((void**)&s->h_chg, 2 * YH_MAX_FRUSTA * 4, hipHostMallocMapped));
         HIP_TRY(ctx, hipHostGetDevicePointer((void**)&s->h_chg_dev, s->h_chg, 0));
@@ -856,6 +863,8 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     a.wdirty = s->wdirty;
     a.bcount = s->counts + YH_MAX_FRUSTA * (1 + s->bparity);
     a.vismask = s->vismask;
+    a.viscnt = s->viscnt;
+    a.cnt_stride = s->cnt_stride;
     a.n_chunks = s->n_chunks;
     a.n_frusta = cull ? n_frusta : 0;
     a.id_base = s->desc.id_base;
@@ -946,11 +955,13 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         // PostWorldTransform / PostLocalTransform (PostTransformSystem.zig:12-37)
         if (s->track) {
             hipLaunchKernelGGL(k_sweep_dirty, dim3(cdiv(s->stride, YH_BLOCK)), dim3(YH_BLOCK), 0, st, s->ldirty, s->wdirty,
-                               (uint32_t)s->n, s->chg_words);
+                               (uint32_t)s->n, s->chg_words, s->chg_cnt);
             HIP_TRY(ctx, hipGetLastError());
             ExpandArgs c;
             memset(&c, 0, sizeof c);
             c.vismask = s->chg_words;
+            c.viscnt = s->chg_cnt;
+            c.cnt_stride = s->cnt_stride;
             c.tilecnt = s->chg_tilecnt;
             c.counts = s->chg;
             c.bcount_cur = s->chg + YH_MAX_FRUSTA;
@@ -984,6 +995,8 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         ExpandArgs x;
         memset(&x, 0, sizeof x);
         x.vismask = s->vismask;
+        x.viscnt = s->viscnt;
+        x.cnt_stride = s->cnt_stride;
         x.tilecnt = s->tilecnt;
         x.counts = s->counts;
         x.bcount_cur = s->counts + YH_MAX_FRUSTA * (1 + s->bparity);
