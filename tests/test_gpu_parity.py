@@ -315,6 +315,62 @@ def test_draw_list_consumer_object_data_and_draw_records(ctx, oracle):
         assert np.array_equal(c[:, 0], per_mesh[ids[lst]])
 
 
+@pytest.mark.parametrize("n,nm,base", [(200_000, 16, 4096), (3_000_000, 16, 0), (50_000, 256, 7), (1000, 1, 0), (100_000, 3, 0)])
+def test_mesh_buckets_are_a_stable_sort_of_the_draw_list(ctx, oracle, n, nm, base):
+    """visible entities grouped by mesh id, ascending entity inside a mesh (= numpy's stable argsort
+    of the list's mesh ids); records, matrices and the bucket table follow that order.  Replaying the reference's draw
+    loop (RenderApi.zig:1410-1441) over the result binds every mesh exactly once."""
+    from yume_amd import Scene, _lib
+
+    trs = oracle.synth_trs(n, n)
+    ids = oracle.synth_mesh_ids(n, nm)
+    per_mesh = np.arange(nm, dtype=np.uint32) * 36 + 12
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    with Scene(ctx, n, n_frusta=1, bounds_kind=2, max_meshes=nm, id_base=base) as s:
+        s.upload_flat()
+        s.upload_trs(trs)
+        s.upload_mesh_aabbs(oracle.synth_mesh_table(nm))
+        s.upload_mesh_ids(ids)
+        s.upload_vertex_counts(per_mesh)
+        with pytest.raises(_lib.YumeHipError):
+            s.mesh_buckets(0)  # no frame yet
+        exp = oracle.frame_trs(trs, np.full(n, 0xFFFFFFFF, np.uint32), np.array([0, n], np.uint32), n_threads=8)
+        for rep in range(2):  # the second pass reuses the scratch of the first
+            s.frame(planes)
+            lst = s.draw_list(0)
+            loc = lst - np.uint32(base)
+            order = np.argsort(ids[loc], kind="stable")
+            b, got_ids, m, c = s.mesh_buckets(0, batch_offset=100 * rep)
+            assert np.array_equal(got_ids, lst[order])
+            assert_same_values(m, exp["m"][loc[order]], "bucketed object data")
+            assert np.array_equal(c[:, 0], per_mesh[ids[loc[order]]]) and np.all(c[:, 1] == 1) and np.all(c[:, 2] == 0)
+            assert np.array_equal(c[:, 3], 100 * rep + np.arange(lst.size, dtype=np.uint32))
+            cnt = np.bincount(ids[loc], minlength=nm).astype(np.uint32)
+            assert np.array_equal(b[:, 0], np.arange(nm)) and np.array_equal(b[:, 2], cnt)
+            assert np.array_equal(b[:, 1], np.cumsum(cnt) - cnt)
+            # the reference's rebinding rule over the bucketed order: one vertex-buffer bind per mesh present
+            meshes = ids[got_ids - np.uint32(base)]
+            binds = 1 + np.count_nonzero(meshes[1:] != meshes[:-1]) if meshes.size else 0
+            assert binds == np.count_nonzero(cnt)
+        # the list-order consumer still works on the same buffers afterwards
+        m2, c2 = s.object_data(0)
+        assert_same_values(m2, exp["m"][loc], "list-order object data after bucketing")
+        with pytest.raises(_lib.YumeHipError) as e:
+            _lib.check(_lib.lib().yh_get_mesh_buckets(s._h, 0, None, 0, None, 0, None))
+        assert e.value.code == _lib.YH_ERR_BAD_ARG
+
+
+def test_mesh_buckets_need_a_mesh_table(ctx, oracle):
+    from yume_amd import _lib
+
+    lo, par, trs, bounds = make_scene(oracle, 5000, 2)
+    with gpu_scene(ctx, lo, par, trs, bounds, 1) as s:
+        s.frame(oracle.main_camera_planes().reshape(1, 24))
+        with pytest.raises(_lib.YumeHipError) as e:
+            s.mesh_buckets(0)
+        assert e.value.code == _lib.YH_ERR_STATE
+
+
 def test_boundary_cases_are_counted(ctx, oracle):
     """Entities placed exactly on / within 1e-5 of a plane are reported in boundary_counts."""
     from yume_amd import Scene

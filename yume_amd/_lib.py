@@ -116,6 +116,8 @@ SIGNATURES = {
     "yh_build_object_data": (_int, [_vp, _u32, _u32]),
     "yh_get_object_data": (_int, [_vp, _u32, _vp, _vp, _u64, C.POINTER(_u64)]),
     "yh_object_data_device": (_vp, [_vp, _u32, C.POINTER(_vp)]),
+    "yh_build_mesh_buckets": (_int, [_vp, _u32, _u32]),
+    "yh_get_mesh_buckets": (_int, [_vp, _u32, _vp, _u32, _vp, _u64, C.POINTER(_u64)]),
     "yh_allgather_draw_lists_async": (_int, [_vp]),
     "yh_get_gathered_counts": (_int, [_vp, _vp]),
     "yh_decompose": (_int, [_vp, _int, _vp, _vp, _u64, _u64]),

@@ -93,6 +93,7 @@ class Scene:
         self.n_frusta = int(n_frusta)
         self.local_kind = local_kind
         self.bounds_kind = bounds_kind
+        self.max_meshes = self.n_meshes = int(max_meshes)
         d = L.SceneDesc(self.n, self.n_levels, self.n_frusta, local_kind, bounds_kind, max_meshes, id_base,
                         draw_capacity)
         self._h = C.c_void_p()
@@ -148,6 +149,7 @@ class Scene:
     def upload_mesh_aabbs(self, table):
         table = np.ascontiguousarray(table, np.float32).reshape(-1, 6)
         self._ck(L.lib().yh_upload_mesh_aabbs(self._h, _ptr(table), table.shape[0]))
+        self.n_meshes = table.shape[0]
 
     def upload_mesh_ids(self, ids, first=0):
         ids = np.ascontiguousarray(ids, np.uint32)
@@ -168,6 +170,7 @@ class Scene:
     def fill_synthetic(self, seed=0x59554D45, index_base=0):
         d = L.SynthDesc(seed, index_base)
         self._ck(L.lib().yh_scene_fill_synthetic(self._h, C.byref(d)))
+        self.n_meshes = self.max_meshes
 
     def set_grouping(self, max_group_levels):
         self._ck(L.lib().yh_scene_set_grouping(self._h, int(max_group_levels)))
@@ -243,6 +246,23 @@ class Scene:
         self._ck(L.lib().yh_get_object_data(self._h, frustum, _ptr(m), _ptr(c), k, C.byref(wr)))
         assert wr.value == k
         return m, c
+
+    def mesh_buckets(self, frustum=0, batch_offset=0):
+        """Visible entities grouped by mesh id: (buckets [n_meshes,3] = mesh/first/count, bucket-ordered global ids
+        [k], model matrices [k,16], draw records [k,4])."""
+        self._ck(L.lib().yh_build_mesh_buckets(self._h, frustum, batch_offset))
+        counts, _ = self.counts()
+        k = int(counts[frustum])
+        nm = int(self.n_meshes)
+        b = np.zeros((nm, 3), np.uint32)
+        ids = np.zeros(k, np.uint32)
+        wr = C.c_uint64()
+        self._ck(L.lib().yh_get_mesh_buckets(self._h, frustum, _ptr(b), nm, _ptr(ids), k, C.byref(wr)))
+        assert wr.value == k
+        m = np.zeros((k, 16), np.float32)
+        c = np.zeros((k, 4), np.uint32)
+        self._ck(L.lib().yh_get_object_data(self._h, frustum, _ptr(m), _ptr(c), k, C.byref(wr)))
+        return b, ids, m, c
 
     # ---- sparse rows / change tracking (Mat4 scenes) ----
     def upload_local_rows(self, slots, rows):

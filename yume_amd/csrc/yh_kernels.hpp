@@ -675,6 +675,150 @@ __global__ __launch_bounds__(YH_BLOCK) void k_build_objects(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Per-mesh bucketing of a draw list.  The reference's draw loop rebinds the vertex buffer
+// whenever "mesh != previous mesh" (RenderApi.zig:1434): handing it the visible entities grouped by mesh makes that
+// one bind per mesh.  A stable counting sort by mesh id: YH_BUCKET_WAVES waves own one contiguous slice of the
+// (ascending) list each; pass 1 histograms the slices, two small launches turn hist[mesh][wave] into output offsets,
+// pass 2 walks every slice again in order and scatters entity id, model matrix and draw record — so inside a
+// bucket the entities stay in ascending order.
+#define YH_BUCKET_WAVES 8192u
+#define YH_BUCKET_MAX_MESHES 256u
+
+struct BucketArgs {
+    const uint32_t* list;       // the frustum's draw list (global ids, ascending)
+    const uint32_t* count_ptr;  // its length, on the device
+    uint64_t cap;
+    uint32_t id_base;
+    const uint32_t* mesh_id;
+    uint32_t n_meshes;
+    uint32_t* hist;    // [n_meshes][YH_BUCKET_WAVES] counts, then (k_bucket_rows) exclusive offsets inside the row
+    uint32_t* totals;  // [n_meshes]
+    uint32_t* starts;  // [n_meshes] first output position of each bucket
+    uint32_t* buckets; // [n_meshes] x {mesh, first, count}
+    const float* world;
+    const uint32_t* vcount;
+    uint32_t batch_offset;
+    uint32_t* out_list;
+    uint32_t* obj;
+    uint4* cmds;
+};
+
+__device__ __forceinline__ void bucket_slice(const BucketArgs& a, uint32_t gw, uint64_t& lo, uint64_t& hi) {
+    uint64_t count = *a.count_ptr;
+    if (count > a.cap) count = a.cap;
+    uint64_t per = (count + YH_BUCKET_WAVES - 1) / YH_BUCKET_WAVES;
+    per = (per + 63u) & ~(uint64_t)63u;
+    lo = (uint64_t)gw * per;
+    hi = lo + per;
+    if (lo > count) lo = count;
+    if (hi > count) hi = count;
+}
+
+__global__ __launch_bounds__(YH_BLOCK) void k_bucket_hist(BucketArgs a) {
+    __shared__ uint32_t h[YH_BLOCK / 64][YH_BUCKET_MAX_MESHES];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t gw = blockIdx.x * (YH_BLOCK / 64) + wave;
+    for (uint32_t m = lane; m < a.n_meshes; m += 64) h[wave][m] = 0;
+    __syncthreads();
+    uint64_t lo, hi;
+    bucket_slice(a, gw, lo, hi);
+    for (uint64_t i = lo + lane; i < hi; i += 64) atomicAdd(&h[wave][a.mesh_id[a.list[i] - a.id_base]], 1u);
+    __syncthreads();
+    for (uint32_t m = lane; m < a.n_meshes; m += 64) a.hist[(uint64_t)m * YH_BUCKET_WAVES + gw] = h[wave][m];
+}
+
+// One workgroup per mesh: exclusive scan of the row's YH_BUCKET_WAVES counts (32 per thread), total to totals[m].
+__global__ __launch_bounds__(YH_BLOCK) void k_bucket_rows(BucketArgs a) {
+    constexpr uint32_t PER = YH_BUCKET_WAVES / YH_BLOCK;
+    __shared__ uint32_t part[YH_BLOCK];
+    uint32_t* row = a.hist + (uint64_t)blockIdx.x * YH_BUCKET_WAVES + threadIdx.x * PER;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) {
+        v[i] = row[i];
+        sum += v[i];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < YH_BLOCK; d <<= 1) {
+        const uint32_t t = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) {
+        row[i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == YH_BLOCK - 1) a.totals[blockIdx.x] = part[threadIdx.x];
+}
+
+// One workgroup: bucket starts = exclusive scan of the totals; the bucket table the renderer reads.
+__global__ __launch_bounds__(YH_BUCKET_MAX_MESHES) void k_bucket_starts(BucketArgs a) {
+    __shared__ uint32_t part[YH_BUCKET_MAX_MESHES];
+    const uint32_t m = threadIdx.x;
+    const uint32_t total = m < a.n_meshes ? a.totals[m] : 0u;
+    part[m] = total;
+    __syncthreads();
+    for (uint32_t d = 1; d < YH_BUCKET_MAX_MESHES; d <<= 1) {
+        const uint32_t t = m >= d ? part[m - d] : 0u;
+        __syncthreads();
+        part[m] += t;
+        __syncthreads();
+    }
+    if (m < a.n_meshes) {
+        const uint32_t first = part[m] - total;
+        a.starts[m] = first;
+        a.buckets[3 * m + 0] = m;
+        a.buckets[3 * m + 1] = first;
+        a.buckets[3 * m + 2] = total;
+    }
+}
+
+__global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
+    __shared__ uint32_t base_s[YH_BLOCK / 64][YH_BUCKET_MAX_MESHES];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t gw = blockIdx.x * (YH_BLOCK / 64) + wave;
+    volatile uint32_t* base = base_s[wave];  // private to the wave: its next output position per mesh
+    for (uint32_t m = lane; m < a.n_meshes; m += 64) base[m] = a.starts[m] + a.hist[(uint64_t)m * YH_BUCKET_WAVES + gw];
+    __syncthreads();
+    uint64_t lo, hi;
+    bucket_slice(a, gw, lo, hi);
+    for (uint64_t i0 = lo; i0 < hi; i0 += 64) {  // wave-uniform trip count
+        const uint64_t i = i0 + lane;
+        const bool active = i < hi;
+        const uint32_t id = active ? a.list[i] : 0u;
+        const uint32_t e = id - a.id_base;
+        const uint32_t m = active ? a.mesh_id[e] : 0xFFFFFFFFu;
+        uint32_t pos = 0;
+        uint64_t todo = __ballot(active);
+        while (todo) {  // one turn per distinct mesh among the 64 entries
+            const int leader = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t lm = __shfl(m, leader);
+            const uint64_t same = __ballot(m == lm);
+            if (m == lm) pos = base[lm] + __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
+            __builtin_amdgcn_wave_barrier();
+            if ((int)lane == leader) base[lm] = base[lm] + (uint32_t)__popcll(same);
+            __builtin_amdgcn_wave_barrier();
+            todo &= ~same;
+        }
+        // (staging the rows through LDS so that four lanes write one 64-byte row together was measured 9 % slower)
+        if (active) {
+            a.out_list[pos] = id;
+            a.cmds[pos] = make_uint4(a.vcount ? a.vcount[m] : 0u, 1u, 0u, a.batch_offset + pos);
+            const uint64_t off = eoff<16>(e);
+            float4* dst = reinterpret_cast<float4*>(a.obj + (uint64_t)pos * 16);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                dst[c] = make_float4(lde(a.world, off, 4 * c), lde(a.world, off, 4 * c + 1), lde(a.world, off, 4 * c + 2),
+                                     lde(a.world, off, 4 * c + 3));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Synthetic scene generator: TRS + bounds from the counter-based hash, bit-identical to
 // the oracle's host generator.  Level 0 (local index < n_level0) draws from the wide ranges.
 __global__ __launch_bounds__(YH_BLOCK) void k_synth(float* __restrict__ trs, float* __restrict__ bounds,

@@ -78,6 +78,11 @@ struct yh_scene {
     uint32_t* obj[YH_MAX_FRUSTA] = {};
     uint4* cmd[YH_MAX_FRUSTA] = {};
     uint32_t* vcount = nullptr;       // vertices per mesh (mesh-table scenes) or per entity
+    // per-mesh buckets (yh_build_mesh_buckets): bucketed entity ids + bucket table per frustum, shared scratch
+    uint32_t* blist[YH_MAX_FRUSTA] = {};
+    uint32_t* bkt[YH_MAX_FRUSTA] = {};
+    uint32_t* bscratch = nullptr;     // hist [n_meshes][YH_BUCKET_WAVES] | totals | starts
+    bool bucketed[YH_MAX_FRUSTA] = {};
     void* staging = nullptr;          // device staging for AoS68 import/export
     uint64_t staging_bytes = 0;
     std::vector<uint32_t> level_offsets;
@@ -222,7 +227,10 @@ static void scene_free(yh_scene* s) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->vcount) (void)hipFree(s->vcount);
+    if (s->bscratch) (void)hipFree(s->bscratch);
     for (uint32_t f = 0; f < YH_MAX_FRUSTA; ++f) {
+        if (s->blist[f]) (void)hipFree(s->blist[f]);
+        if (s->bkt[f]) (void)hipFree(s->bkt[f]);
         if (s->obj[f]) (void)hipFree(s->obj[f]);
         if (s->cmd[f]) (void)hipFree(s->cmd[f]);
         if (s->draw[f]) (void)hipFree(s->draw[f]);
@@ -1094,6 +1102,72 @@ extern "C" int yh_build_object_data(yh_scene* s, uint32_t frustum, uint32_t batc
                        s->cmd[frustum]);
     HIP_TRY(ctx, hipGetLastError());
     s->frame_pending = true;
+    s->bucketed[frustum] = false;
+    return YH_OK;
+}
+
+// Per-mesh bucketing: the same object data and draw records, grouped by mesh id.
+extern "C" int yh_build_mesh_buckets(yh_scene* s, uint32_t frustum, uint32_t batch_offset) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_build_mesh_buckets: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    if (s->desc.bounds_kind != YH_BOUNDS_MESH_TABLE)
+        return fail(ctx, YH_ERR_STATE, "yh_build_mesh_buckets: the scene has no mesh table (entities carry no mesh id)");
+    if (frustum >= s->last_n_frusta) return fail(ctx, YH_ERR_STATE, "yh_build_mesh_buckets: frustum %u was not culled by the last frame", frustum);
+    if (s->n_meshes < 1 || s->n_meshes > YH_BUCKET_MAX_MESHES)
+        return fail(ctx, YH_ERR_UNSUPPORTED, "yh_build_mesh_buckets: %u meshes, 1..%u supported", s->n_meshes, YH_BUCKET_MAX_MESHES);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!s->obj[frustum]) {
+        HIP_TRY(ctx, hipMalloc((void**)&s->obj[frustum], s->draw_cap * 64));
+        HIP_TRY(ctx, hipMalloc((void**)&s->cmd[frustum], s->draw_cap * 16));
+    }
+    const uint32_t M = std::min<uint32_t>(s->desc.max_meshes, YH_BUCKET_MAX_MESHES);
+    if (!s->blist[frustum]) {
+        HIP_TRY(ctx, hipMalloc((void**)&s->blist[frustum], s->draw_cap * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&s->bkt[frustum], (uint64_t)M * 12));
+    }
+    if (!s->bscratch) HIP_TRY(ctx, hipMalloc((void**)&s->bscratch, ((uint64_t)M * YH_BUCKET_WAVES + 2 * M) * 4));
+    BucketArgs a{};
+    a.list = s->draw[frustum];
+    a.count_ptr = s->counts + frustum;
+    a.cap = s->draw_cap;
+    a.id_base = s->desc.id_base;
+    a.mesh_id = s->mesh_id;
+    a.n_meshes = s->n_meshes;
+    a.hist = s->bscratch;
+    a.totals = s->bscratch + (uint64_t)M * YH_BUCKET_WAVES;
+    a.starts = a.totals + M;
+    a.buckets = s->bkt[frustum];
+    a.world = s->world;
+    a.vcount = s->vcount;
+    a.batch_offset = batch_offset;
+    a.out_list = s->blist[frustum];
+    a.obj = s->obj[frustum];
+    a.cmds = s->cmd[frustum];
+    const dim3 grid(YH_BUCKET_WAVES / (YH_BLOCK / 64));
+    hipLaunchKernelGGL(k_bucket_hist, grid, dim3(YH_BLOCK), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_bucket_rows, dim3(s->n_meshes), dim3(YH_BLOCK), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_bucket_starts, dim3(1), dim3(YH_BUCKET_MAX_MESHES), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_bucket_scatter, grid, dim3(YH_BLOCK), 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    s->frame_pending = true;
+    s->bucketed[frustum] = true;
+    return YH_OK;
+}
+
+extern "C" int yh_get_mesh_buckets(yh_scene* s, uint32_t frustum, yh_bucket* buckets, uint32_t cap_buckets,
+                                   uint32_t* entities, uint64_t cap, uint64_t* written) {
+    if (!s || !written) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_get_mesh_buckets: NULL argument");
+    yh_ctx* ctx = s->ctx;
+    if (frustum >= YH_MAX_FRUSTA || !s->bucketed[frustum]) return fail(ctx, YH_ERR_STATE, "yh_get_mesh_buckets: call yh_build_mesh_buckets first");
+    if (int rc = sync_scene(s)) return rc;
+    const uint64_t n = std::min<uint64_t>(s->h_counts[frustum], s->draw_cap);
+    *written = n;
+    if (buckets && cap_buckets < s->n_meshes)
+        return fail(ctx, YH_ERR_CAPACITY, "yh_get_mesh_buckets: %u buckets, room for %u", s->n_meshes, cap_buckets);
+    if (entities && n > cap) return fail(ctx, YH_ERR_CAPACITY, "yh_get_mesh_buckets: %llu entities, room for %llu", (unsigned long long)n, (unsigned long long)cap);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (buckets) HIP_TRY(ctx, hipMemcpy(buckets, s->bkt[frustum], (uint64_t)s->n_meshes * 12, hipMemcpyDeviceToHost));
+    if (entities && n) HIP_TRY(ctx, hipMemcpy(entities, s->blist[frustum], n * 4, hipMemcpyDeviceToHost));
     return YH_OK;
 }
 

@@ -69,6 +69,9 @@ pub extern fn yh_camera_view_projection(orthographic: c_int, pos: *const [3]f32,
 pub extern fn yh_upload_vertex_counts(s: *Scene, counts: [*]const u32, n: u64) c_int;
 pub extern fn yh_build_object_data(s: *Scene, frustum: u32, batch_offset: u32) c_int;
 pub extern fn yh_object_data_device(s: *Scene, frustum: u32, cmds_device: ?*?*anyopaque) ?*anyopaque;
+pub const Bucket = extern struct { mesh: u32, first: u32, count: u32 };
+pub extern fn yh_build_mesh_buckets(s: *Scene, frustum: u32, batch_offset: u32) c_int;
+pub extern fn yh_get_mesh_buckets(s: *Scene, frustum: u32, buckets: ?[*]Bucket, cap_buckets: u32, entities: ?[*]u32, cap: u64, written: *u64) c_int;
 pub extern fn yh_decompose(s: *Scene, which: c_int, planes: *const [10][*]f32, valid: ?[*]u8, first: u64, count: u64) c_int;
 pub extern fn yh_extract_planes(view_projection: *const [16]f32, planes: *[24]f32) void;
 
