@@ -278,8 +278,9 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         use_lib_comm = bool(flag.item())
-        collective = ("rccl (library, collective stream): allgather(counts) + allgather(lists padded to capacity) + pack, "
-                      "overlapping the next frame's transforms" if use_lib_comm
+        collective = ("rccl (library, collective stream): one ncclAllGather of the frame's visibility words (n/8 bytes per "
+                      "frustum and rank), every rank expands all ranks' words into the gathered lists; runs beside the next "
+                      "frames" if use_lib_comm
                       else f"torch.distributed nccl stand-by (library communicator failed: {err[:120]})")
 
     def step():

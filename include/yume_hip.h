@@ -280,10 +280,18 @@ void yh_comm_destroy(yh_ctx* ctx);
 /* All-gather of per-rank visible counts, then of the compacted draw lists (exact sizes, written at
  * prefix-sum offsets into a library-owned gathered list per frustum).  all_counts: n_ranks x n_frusta.   */
 int yh_allgather_draw_lists(yh_scene* s, uint32_t* all_counts /* may be NULL */);
-/* The same exchange without a host round trip: everything is enqueued on the context's collective stream behind
- * this frame and overlaps the next frame's transform launches; lists travel padded to draw_capacity.  Counts and
- * lists are read afterwards with yh_get_gathered_counts / yh_get_gathered_draw_list (they synchronise).     */
+/* The same result without a host round trip: everything is enqueued on the context's collective stream behind
+ * this frame and runs beside the next frames' launches.  What crosses xGMI is the frame's visibility words (one bit
+ * per entity and frustum: a fixed size, one ncclAllGather, 20-32x fewer bytes than the lists); every rank expands
+ * all ranks' words into the gathered lists itself, rank order, each rank's id_base added.  The gathered lists hold
+ * every visible entity even where a rank's own draw_capacity was too small for its list.  The first call on a scene
+ * synchronises once (ranks exchange word counts and id bases; every rank must have created the scene with the same
+ * n_frusta).  Counts and lists are read afterwards with yh_get_gathered_counts / yh_get_gathered_draw_list (they
+ * synchronise).                                                                                                  */
 int yh_allgather_draw_lists_async(yh_scene* s);
+/* Testing aid (one GPU, no communicator): runs the gather's expansion on fake_ranks copies of this scene's own
+ * words, rank r owning ids id_base + r * n_entities; read the result like a real gather's.                      */
+int yh_gather_selftest(yh_scene* s, uint32_t fake_ranks);
 int yh_get_gathered_counts(yh_scene* s, uint32_t* all_counts /* n_ranks x n_frusta */);
 int yh_get_gathered_draw_list(yh_scene* s, uint32_t frustum, uint32_t* out, uint64_t cap, uint64_t* written);
 

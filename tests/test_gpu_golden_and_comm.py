@@ -86,6 +86,31 @@ def test_rccl_one_rank_allgather_without_host_sync(oracle):
             assert np.array_equal(s.gathered_draw_list(1, counts[1]), s.draw_list(1))
 
 
+@pytest.mark.parametrize("n,levels,ranks,base", [(100_000, 3, 8, 0), (1_000_000, 1, 4, 5000), (777, 1, 3, 0), (20_000_000, 1, 2, 0)])
+def test_gather_expansion_with_several_ranks_on_one_gpu(ctx, oracle, n, levels, ranks, base):
+    """The no-sync gather sends visibility words and every rank expands all ranks' words itself.  One GPU cannot run
+    a real R-rank exchange, so yh_gather_selftest feeds that expansion R copies of this scene's own words (rows
+    zero-padded as for a shorter shard), rank r owning ids id_base + r*n: the gathered list has to be the scene's own
+    list R times, shifted, and the per-rank counts the scene's counts."""
+    from yume_amd import Scene
+
+    planes = np.concatenate([oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()[:2]])
+    lo = oracle.synth_level_offsets(n, levels)
+    with Scene(ctx, n, n_levels=levels, n_frusta=3, id_base=base) as s:
+        s.upload_hierarchy(oracle.synth_parents(lo), lo)
+        s.fill_synthetic()
+        for nf in (3, 2):  # the second pass with fewer frusta than the scene was created for
+            s.frame(planes[:nf])
+            counts, _ = s.counts()
+            s.gather_selftest(ranks)
+            gc = s.gathered_counts(nf, n_ranks=ranks)
+            assert gc.shape == (ranks, nf) and np.all(gc == counts[:nf][None, :])
+            for f in range(nf):
+                own = s.draw_list(f).astype(np.int64)
+                exp = np.concatenate([own + r * n for r in range(ranks)]).astype(np.uint32)
+                assert np.array_equal(s.gathered_draw_list(f, gc[:, f].sum()), exp), f"frustum {f}"
+
+
 def test_allgather_without_communicator_is_a_state_error(ctx, oracle):
     from yume_amd import Scene, _lib
 

@@ -345,8 +345,12 @@ class Scene:
         """Enqueue the exchange (no host sync); read with gathered_counts() / gathered_draw_list()."""
         self._ck(L.lib().yh_allgather_draw_lists_async(self._h))
 
-    def gathered_counts(self, n_frusta):
-        out = np.zeros((self.ctx.n_ranks, max(1, n_frusta)), np.uint32)
+    def gather_selftest(self, fake_ranks):
+        """One-GPU rehearsal of the gather's expansion: fake_ranks copies of this scene's own visibility words."""
+        self._ck(L.lib().yh_gather_selftest(self._h, int(fake_ranks)))
+
+    def gathered_counts(self, n_frusta, n_ranks=None):
+        out = np.zeros((n_ranks or self.ctx.n_ranks, max(1, n_frusta)), np.uint32)
         self._ck(L.lib().yh_get_gathered_counts(self._h, _ptr(out)))
         return out
 

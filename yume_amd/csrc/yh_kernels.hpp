@@ -625,23 +625,69 @@ __global__ __launch_bounds__(YH_BLOCK) void k_soa_to_aos68(const float* __restri
     for (uint32_t i = threadIdx.x; i < ndw; i += YH_BLOCK) rows[r0 * 17 + i] = tile[i];
 }
 
-// Multi-GPU, no-host-sync gather: every rank's list arrives padded to the list capacity ([rank][cap]); the counts
-// arrive by their own all-gather.  One pass packs the R lists back to back (rank order = ascending global ids when
-// shards own ascending id ranges).  grid = (cap / 256, R).
-__global__ __launch_bounds__(YH_BLOCK) void k_compact_gathered(const uint32_t* __restrict__ padded,
-                                                               const uint32_t* __restrict__ all_counts, uint32_t frustum,
-                                                               uint64_t cap, uint32_t* __restrict__ out) {
-    const uint32_t r = blockIdx.y;
-    uint64_t count = all_counts[r * YH_K_MAX_FRUSTA + frustum];
-    if (count > cap) count = cap;
-    const uint64_t i = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;
-    if (i >= count) return;
-    uint64_t off = 0;
-    for (uint32_t q = 0; q < r; ++q) {
-        const uint64_t c = all_counts[q * YH_K_MAX_FRUSTA + frustum];
-        off += c < cap ? c : cap;
+// Multi-GPU, no-host-sync gather.  What crosses xGMI is the visibility WORDS, not the lists: one bit per entity
+// instead of four bytes per visible entity (32x fewer bytes than lists padded to capacity, and a fixed size, so a
+// single ncclAllGather needs no counts first).  Every rank then expands all R masks itself, exactly as k_count /
+// k_expand do for its own: gmask = [rank][frustum][words] (rows zero-padded to the longest shard), output = the R
+// lists back to back in rank order with each rank's id_base added (ascending global ids when shards own ascending id
+// ranges).  grid = (tiles of 256 words, frusta, ranks).
+struct GatherArgs {
+    const uint64_t* gmask;    // [R][F][words]
+    const uint32_t* peer;     // [R][4]: n_chunks, id_base, frusta, -
+    uint32_t* gtile;          // [F][R][n_tiles]
+    uint32_t* cum;            // [R][YH_K_MAX_FRUSTA]: entries of ranks 0..r in frustum f (running total)
+    uint32_t* out[YH_K_MAX_FRUSTA];
+    uint32_t words, n_tiles, n_ranks, n_frusta;
+};
+
+__global__ __launch_bounds__(YH_BLOCK) void k_gather_count(const GatherArgs g) {
+    __shared__ uint32_t s_red[4];
+    const uint32_t t = blockIdx.x, f = blockIdx.y, r = blockIdx.z;
+    const uint32_t c = t * YH_BLOCK + threadIdx.x;
+    const uint64_t m = c < g.words ? g.gmask[((uint64_t)r * g.n_frusta + f) * g.words + c] : 0ull;
+    const uint32_t total = block_sum_256((uint32_t)__popcll(m), s_red);
+    if (threadIdx.x == 0) g.gtile[((uint64_t)f * g.n_ranks + r) * g.n_tiles + t] = total;
+}
+
+__global__ __launch_bounds__(YH_BLOCK) void k_gather_expand(const GatherArgs g) {
+    __shared__ uint32_t s_red[4];
+    __shared__ uint32_t s_off[YH_BLOCK];
+    __shared__ uint64_t s_mask[YH_BLOCK];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t t = blockIdx.x, f = blockIdx.y, r = blockIdx.z;
+    const uint32_t c0 = t * YH_BLOCK, c = c0 + tid;
+    const uint64_t m = c < g.words ? g.gmask[((uint64_t)r * g.n_frusta + f) * g.words + c] : 0ull;
+    const uint32_t pc = (uint32_t)__popcll(m);
+    // base = entries of the ranks before this one and of this rank's tiles before this one
+    const uint32_t* __restrict__ cnt = g.gtile + (uint64_t)f * g.n_ranks * g.n_tiles;
+    const uint32_t before = r * g.n_tiles + t;
+    uint32_t part = 0;
+    for (uint32_t i = tid; i < before; i += YH_BLOCK) part += cnt[i];
+    const uint32_t base = block_sum_256(part, s_red);
+    uint32_t inc = pc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o);
+        if ((int)lane >= o) inc += v;
     }
-    out[off + i] = padded[(uint64_t)r * cap + i];
+    if (lane == 63) s_red[wv] = inc;
+    s_mask[tid] = m;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < wv; ++w) wbase += s_red[w];
+    s_off[tid] = wbase + inc - pc;
+    const uint32_t own = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    if (tid == 0 && t + 1 == g.n_tiles) g.cum[r * YH_K_MAX_FRUSTA + f] = base + own;
+    if (own == 0) return;
+    uint32_t* __restrict__ out = g.out[f];
+    const uint32_t id_base = g.peer[r * 4 + 1];
+    const uint32_t n_words = min((uint32_t)YH_BLOCK, g.words - c0);
+#pragma unroll 8
+    for (uint32_t k = wv; k < n_words; k += 4) {
+        const uint64_t mk = s_mask[k];  // wave-uniform
+        if (mk && ((mk >> lane) & 1ull)) out[(uint64_t)base + s_off[k] + lane_rank(mk)] = ((c0 + k) << 6) + lane + id_base;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -112,11 +112,24 @@ struct yh_scene {
     uint32_t* gathered[YH_MAX_FRUSTA] = {};
     uint64_t gathered_cap[YH_MAX_FRUSTA] = {};
     uint64_t gathered_len[YH_MAX_FRUSTA] = {};
-    // no-host-sync gather (yh_allgather_draw_lists_async)
-    uint32_t* padded[YH_MAX_FRUSTA] = {};  // [rank][draw_cap] receive buffers
-    hipEvent_t ev_frame = nullptr, ev_comm = nullptr;
-    bool comm_pending = false;    // the next expansion must wait for ev_comm: the gather still reads the lists
-    bool gathered_async = false;  // gathered_len is to be derived from h_all_counts after a sync
+    // no-host-sync gather (yh_allgather_draw_lists_async): the visibility words travel, every rank expands them
+    bool g_ready = false;
+    int g_ranks = 0;                  // ranks the buffers below were sized for
+    int counts_cap = 0;               // ranks d_all_counts / h_all_counts have room for
+    int counts_ranks = 0;             // ranks the host counts currently describe
+    uint32_t g_words = 0, g_tiles = 0, g_frusta = 0;  // longest shard's words per frustum row, its 256-word tiles
+    uint32_t* d_peer = nullptr;       // [R][4] n_chunks, id_base, frusta, - of every rank (+ 4 words: this rank's own)
+    std::vector<uint32_t> h_peer;
+    uint64_t* gmask = nullptr;        // [R][F][g_words] received words
+    uint64_t* send_pad = nullptr;     // [F][g_words] zero-padded copy of this rank's words (only if n_chunks < g_words)
+    uint32_t* gtile = nullptr;        // [F][R][g_tiles]
+    uint64_t* mask_alt = nullptr;     // second set of visibility words: frames alternate, so a frame's words stay
+    uint32_t mparity = 0;             //   intact while the collective stream sends them (next frame writes the other set)
+    uint64_t* last_mask = nullptr;    // the words the last culling frame wrote
+    uint32_t last_mparity = 0;
+    hipEvent_t ev_frame = nullptr, ev_comm = nullptr, ev_mask[2] = {nullptr, nullptr};
+    bool mask_busy[2] = {false, false};  // ev_mask[p] must have passed before a frame writes word set p again
+    bool gathered_async = false;  // h_all_counts holds running totals to be turned into counts after a sync
 };
 
 static thread_local std::string g_err;
@@ -235,13 +248,16 @@ static void scene_free(yh_scene* s) {
         if (s->cmd[f]) (void)hipFree(s->cmd[f]);
         if (s->draw[f]) (void)hipFree(s->draw[f]);
         if (s->gathered[f]) (void)hipFree(s->gathered[f]);
-        if (s->padded[f]) (void)hipFree(s->padded[f]);
     }
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     if (s->h_chg) (void)hipHostFree(s->h_chg);
     if (s->h_all_counts) (void)hipHostFree(s->h_all_counts);
     if (s->ev_frame) (void)hipEventDestroy(s->ev_frame);
     if (s->ev_comm) (void)hipEventDestroy(s->ev_comm);
+    for (hipEvent_t e : s->ev_mask)
+        if (e) (void)hipEventDestroy(e);
+    for (void* p : {(void*)s->d_peer, (void*)s->gmask, (void*)s->send_pad, (void*)s->gtile, (void*)s->mask_alt})
+        if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (hipEvent_t e : s->kev)
@@ -683,7 +699,7 @@ extern "C" int yh_scene_track_changes(yh_scene* s, int enable) {
         const uint64_t tile_words = ((uint64_t)s->n_tiles + 1) & ~1ull;
         const uint64_t bytes = (32 + tile_words) * 4 + (uint64_t)s->n_chunks * 8 + s->cnt_stride + 16;
         HIP_TRY(ctx, hipMalloc((void**)&s->chg, bytes));
-        HIP_TRY(ctx, hipMemset(s->chg, 0, bytes));
+        HIP_TRY(ctx, hipMemsetAsync(s->chg, 0, bytes, ctx->stream));  // ordered with the frames: not the null stream
         s->chg_tilecnt = s->chg + 32;
         s->chg_words = (uint64_t*)(s->chg_tilecnt + tile_words);
         s->chg_cnt = (uint8_t*)(((uintptr_t)(s->chg_words + s->n_chunks) + 15) & ~(uintptr_t)15);
@@ -870,7 +886,13 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     a.ldirty = s->ldirty;
     a.wdirty = s->wdirty;
     a.bcount = s->counts + YH_MAX_FRUSTA * (1 + s->bparity);
-    a.vismask = s->vismask;
+    // visibility words: two sets once the no-sync gather is in use (the collective stream still sends the last frame's)
+    uint64_t* const words = (cull && s->mask_alt && s->mparity) ? s->mask_alt : s->vismask;
+    if (cull && s->mask_alt && s->mask_busy[s->mparity]) {
+        HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_mask[s->mparity], 0));
+        s->mask_busy[s->mparity] = false;
+    }
+    a.vismask = words;
     a.viscnt = s->viscnt;
     a.cnt_stride = s->cnt_stride;
     a.n_chunks = s->n_chunks;
@@ -996,13 +1018,12 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     s->root_dirty = 0;  // the world sweep clears the root's flag too
     if (cull) {
         // stage 3, part 2: tile prefix sums + expansion of the visibility words into ordered draw lists
-        if (s->comm_pending) {  // the previous frame's gather (other stream) still reads the lists and totals
-            HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_comm, 0));
-            s->comm_pending = false;
-        }
         ExpandArgs x;
         memset(&x, 0, sizeof x);
-        x.vismask = s->vismask;
+        x.vismask = words;
+        s->last_mask = words;
+        s->last_mparity = s->mparity;
+        if (s->mask_alt) s->mparity ^= 1u;
         x.viscnt = s->viscnt;
         x.cnt_stride = s->cnt_stride;
         x.tilecnt = s->tilecnt;
@@ -1582,6 +1603,21 @@ extern "C" void yh_comm_destroy(yh_ctx* ctx) {
     }
 }
 
+static int ensure_all_counts(yh_scene* s, int R) {
+    yh_ctx* ctx = s->ctx;
+    if (s->d_all_counts && s->counts_cap >= R) return YH_OK;
+    if (int rc = sync_scene(s)) return rc;
+    if (s->d_all_counts) HIP_TRY(ctx, hipFree(s->d_all_counts));
+    if (s->h_all_counts) HIP_TRY(ctx, hipHostFree(s->h_all_counts));
+    s->d_all_counts = nullptr;
+    s->h_all_counts = nullptr;
+    s->counts_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&s->d_all_counts, (size_t)R * YH_MAX_FRUSTA * 4));
+    HIP_TRY(ctx, hipHostMalloc((void**)&s->h_all_counts, (size_t)R * YH_MAX_FRUSTA * 4, hipHostMallocDefault));
+    s->counts_cap = R;
+    return YH_OK;
+}
+
 extern "C" int yh_allgather_draw_lists(yh_scene* s, uint32_t* all_counts) {
     if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_allgather_draw_lists: scene is NULL");
     yh_ctx* ctx = s->ctx;
@@ -1590,13 +1626,11 @@ extern "C" int yh_allgather_draw_lists(yh_scene* s, uint32_t* all_counts) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int R = ctx->n_ranks;
     const uint32_t F = s->last_n_frusta;
-    if (!s->d_all_counts) {
-        HIP_TRY(ctx, hipMalloc((void**)&s->d_all_counts, (size_t)R * YH_MAX_FRUSTA * 4));
-        HIP_TRY(ctx, hipHostMalloc((void**)&s->h_all_counts, (size_t)R * YH_MAX_FRUSTA * 4, hipHostMallocDefault));
-    }
+    if (int rc = ensure_all_counts(s, R)) return rc;
     hipStream_t st = ctx->stream;
     if (int rc = sync_scene(s)) return rc;  // a no-sync gather may still be in flight on the other stream
     s->gathered_async = false;
+    s->counts_ranks = R;
     // (1) per-rank visible counts: 8 x u32 per rank
     RCCL_TRY(ctx, g_rccl.AllGather(s->counts, s->d_all_counts, YH_MAX_FRUSTA, /*ncclUint32*/ 3, ctx->comm, st));
     HIP_TRY(ctx, hipMemcpyAsync(s->h_all_counts, s->d_all_counts, (size_t)R * YH_MAX_FRUSTA * 4, hipMemcpyDeviceToHost, st));
@@ -1642,54 +1676,193 @@ extern "C" int yh_allgather_draw_lists(yh_scene* s, uint32_t* all_counts) {
     return YH_OK;
 }
 
-// The same exchange without a host round trip, for frames that are enqueued back to back: counts by ncclAllGather,
-// every list by an ncclAllGather padded to the list capacity, then one packing kernel per frustum — all on the
-// context's collective stream, behind this frame's launches and beside the next frame's transform launches (only the
-// next expansion, which rewrites the lists, waits for it).  Sends capacity instead of count entries per rank: worth it
-// while a frame is shorter than a host sync (measured: ~40 us frames at 1M entities per GPU).
+// The same result without a host round trip, for frames that are enqueued back to back.  xGMI is point to point
+// (one ~50 GB/s link per peer), so the bytes on the wire decide how this scales: the VISIBILITY WORDS travel (n/8
+// bytes per frustum, a fixed size: one ncclAllGather, no counts needed first) and every rank expands all R masks into
+// the gathered lists itself (k_gather_count / k_gather_expand) — 32x fewer bytes than lists padded to capacity, 20x
+// fewer than exact lists at 64 % visible.  Everything runs on the context's collective stream behind this frame's
+// launches and beside the next frames'; frames alternate between two sets of words, so only the frame after next
+// waits (for the all-gather's read of the set it rewrites).  One-time set-up per scene (host sync): the ranks
+// exchange their word counts and id bases.
+static int gather_setup(yh_scene* s) {
+    yh_ctx* ctx = s->ctx;
+    const int R = ctx->n_ranks;
+    if (s->g_ready && s->g_ranks == R) return YH_OK;
+    if (s->g_ready) return fail(ctx, YH_ERR_STATE, "yh_allgather_draw_lists_async: the communicator changed size under this scene");
+    if (int rc = sync_scene(s)) return rc;
+    const uint32_t F = s->desc.n_frusta;
+    HIP_TRY(ctx, hipMalloc((void**)&s->d_peer, ((size_t)R + 1) * 16));
+    const uint32_t mine[4] = {s->n_chunks, s->desc.id_base, F, 0u};
+    HIP_TRY(ctx, hipMemcpy(s->d_peer + (size_t)R * 4, mine, 16, hipMemcpyHostToDevice));
+    RCCL_TRY(ctx, g_rccl.AllGather(s->d_peer + (size_t)R * 4, s->d_peer, 4, /*ncclUint32*/ 3, ctx->comm, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    s->h_peer.assign((size_t)R * 4, 0u);
+    HIP_TRY(ctx, hipMemcpy(s->h_peer.data(), s->d_peer, (size_t)R * 16, hipMemcpyDeviceToHost));
+    uint32_t words = 0;
+    for (int r = 0; r < R; ++r) {
+        if (s->h_peer[r * 4 + 2] != F)
+            return fail(ctx, YH_ERR_BAD_ARG, "yh_allgather_draw_lists_async: rank %d has %u frusta, this rank %u", r, s->h_peer[r * 4 + 2], F);
+        words = std::max(words, s->h_peer[r * 4 + 0]);
+    }
+    s->g_words = words;
+    s->g_tiles = (words + YH_BLOCK - 1) / YH_BLOCK;
+    s->g_frusta = F;
+    HIP_TRY(ctx, hipMalloc((void**)&s->gmask, (uint64_t)R * F * words * 8));
+    HIP_TRY(ctx, hipMalloc((void**)&s->gtile, (uint64_t)F * R * s->g_tiles * 4));
+    if (s->n_chunks != words) {
+        HIP_TRY(ctx, hipMalloc((void**)&s->send_pad, (uint64_t)F * words * 8));
+        HIP_TRY(ctx, hipMemsetAsync(s->send_pad, 0, (uint64_t)F * words * 8, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMalloc((void**)&s->mask_alt, (uint64_t)F * s->n_chunks * 8));
+    // (on the context's stream and waited for: the null stream's fills are not ordered with our non-blocking streams)
+    HIP_TRY(ctx, hipMemsetAsync(s->mask_alt, 0, (uint64_t)F * s->n_chunks * 8, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t f = 0; f < F; ++f) {
+        const uint64_t cap = (uint64_t)R * words * 64;
+        if (s->gathered_cap[f] < cap) {
+            if (s->gathered[f]) HIP_TRY(ctx, hipFree(s->gathered[f]));
+            s->gathered[f] = nullptr;
+            s->gathered_cap[f] = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&s->gathered[f], cap * 4));
+            s->gathered_cap[f] = cap;
+        }
+    }
+    if (int rc = ensure_all_counts(s, R)) return rc;
+    HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_frame, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming));
+    for (hipEvent_t& e : s->ev_mask) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    s->g_ranks = R;
+    s->g_ready = true;
+    return YH_OK;
+}
+
+// Expansion of the received words on stream sc (shared by the gather and its single-GPU self-test).
+static int gather_expand(yh_scene* s, uint32_t F, hipStream_t sc) {
+    yh_ctx* ctx = s->ctx;
+    GatherArgs g;
+    memset(&g, 0, sizeof g);
+    g.gmask = s->gmask;
+    g.peer = s->d_peer;
+    g.gtile = s->gtile;
+    g.cum = s->d_all_counts;
+    for (uint32_t f = 0; f < YH_MAX_FRUSTA; ++f) g.out[f] = s->gathered[f];
+    g.words = s->g_words;
+    g.n_tiles = s->g_tiles;
+    g.n_ranks = (uint32_t)s->g_ranks;
+    g.n_frusta = F;
+    const dim3 grid(s->g_tiles, F, (uint32_t)s->g_ranks);
+    hipLaunchKernelGGL(k_gather_count, grid, dim3(YH_BLOCK), 0, sc, g);
+    hipLaunchKernelGGL(k_gather_expand, grid, dim3(YH_BLOCK), 0, sc, g);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(s->h_all_counts, s->d_all_counts, (size_t)s->g_ranks * YH_MAX_FRUSTA * 4, hipMemcpyDeviceToHost, sc));
+    s->counts_ranks = s->g_ranks;
+    return YH_OK;
+}
+
 extern "C" int yh_allgather_draw_lists_async(yh_scene* s) {
     if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_allgather_draw_lists_async: scene is NULL");
     yh_ctx* ctx = s->ctx;
     if (!ctx->comm) return fail(ctx, YH_ERR_STATE, "yh_allgather_draw_lists_async: call yh_comm_init first");
-    if (s->frames == 0) return fail(ctx, YH_ERR_STATE, "yh_allgather_draw_lists_async: no frame has run");
+    if (s->frames == 0 || !s->last_mask || s->last_n_frusta == 0)
+        return fail(ctx, YH_ERR_STATE, "yh_allgather_draw_lists_async: no culling frame has run");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int R = ctx->n_ranks;
+    if (int rc = gather_setup(s)) return rc;
     const uint32_t F = s->last_n_frusta;
-    if (!s->d_all_counts) {
-        HIP_TRY(ctx, hipMalloc((void**)&s->d_all_counts, (size_t)R * YH_MAX_FRUSTA * 4));
-        HIP_TRY(ctx, hipHostMalloc((void**)&s->h_all_counts, (size_t)R * YH_MAX_FRUSTA * 4, hipHostMallocDefault));
-    }
-    if (!s->ev_frame) {
-        HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_frame, hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming));
-    }
-    const uint64_t cap = s->draw_cap;
-    for (uint32_t f = 0; f < F; ++f) {
-        if (!s->padded[f]) HIP_TRY(ctx, hipMalloc((void**)&s->padded[f], (uint64_t)R * cap * 4));
-        if (s->gathered_cap[f] < (uint64_t)R * cap) {
-            if (int rc = sync_scene(s)) return rc;
-            if (s->gathered[f]) HIP_TRY(ctx, hipFree(s->gathered[f]));
-            s->gathered[f] = nullptr;
-            s->gathered_cap[f] = 0;
-            HIP_TRY(ctx, hipMalloc((void**)&s->gathered[f], (uint64_t)R * cap * 4));
-            s->gathered_cap[f] = (uint64_t)R * cap;
-        }
-    }
+    const uint32_t W = s->g_words;
     hipStream_t sc = ctx->stream_c;
     HIP_TRY(ctx, hipEventRecord(s->ev_frame, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(sc, s->ev_frame, 0));
-    RCCL_TRY(ctx, g_rccl.AllGather(s->counts, s->d_all_counts, YH_MAX_FRUSTA, /*ncclUint32*/ 3, ctx->comm, sc));
-    for (uint32_t f = 0; f < F; ++f) {
-        RCCL_TRY(ctx, g_rccl.AllGather(s->draw[f], s->padded[f], cap, /*ncclUint32*/ 3, ctx->comm, sc));
-        hipLaunchKernelGGL(k_compact_gathered, dim3(cdiv(cap, YH_BLOCK), R), dim3(YH_BLOCK), 0, sc, s->padded[f], s->d_all_counts, f,
-                           cap, s->gathered[f]);
-        HIP_TRY(ctx, hipGetLastError());
+    const uint64_t* send = s->last_mask;  // [F][n_chunks], rows back to back
+    if (s->send_pad) {                    // shorter shard: rows padded with zero words to the longest one's length
+        HIP_TRY(ctx, hipMemcpy2DAsync(s->send_pad, (size_t)W * 8, s->last_mask, (size_t)s->n_chunks * 8, (size_t)s->n_chunks * 8, F,
+                                      hipMemcpyDeviceToDevice, sc));
+        send = s->send_pad;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(s->h_all_counts, s->d_all_counts, (size_t)R * YH_MAX_FRUSTA * 4, hipMemcpyDeviceToHost, sc));
+    RCCL_TRY(ctx, g_rccl.AllGather(send, s->gmask, (size_t)F * W, /*ncclUint64*/ 5, ctx->comm, sc));
+    HIP_TRY(ctx, hipEventRecord(s->ev_mask[s->last_mparity], sc));
+    s->mask_busy[s->last_mparity] = true;
+    if (int rc = gather_expand(s, F, sc)) return rc;
     HIP_TRY(ctx, hipEventRecord(s->ev_comm, sc));
-    s->comm_pending = true;
     s->gathered_async = true;
     s->frame_pending = true;
+    return YH_OK;
+}
+
+// Testing aid (one GPU): the gather's expansion fed with `fake_ranks` copies of this scene's own words, rank r
+// pretending to own ids id_base + r * n_entities — what R identical shards would have sent.  Results are read with
+// yh_get_gathered_counts / yh_get_gathered_draw_list as after a real gather.
+extern "C" int yh_gather_selftest(yh_scene* s, uint32_t fake_ranks) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_gather_selftest: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    ARG_TRY(ctx, fake_ranks >= 1 && fake_ranks <= 64, "yh_gather_selftest: 1..64 ranks");
+    if (ctx->comm || s->g_ready) return fail(ctx, YH_ERR_STATE, "yh_gather_selftest: not on a scene or context that gathers for real");
+    if (s->frames == 0 || s->last_n_frusta == 0) return fail(ctx, YH_ERR_STATE, "yh_gather_selftest: no culling frame has run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_scene(s)) return rc;
+    const uint32_t R = fake_ranks, F = s->last_n_frusta;
+    // word rows one longer than this scene's, as if another shard were the longest: exercises the zero padding
+    const uint32_t W = s->n_chunks + 3;
+    if (int rc = ensure_all_counts(s, (int)R)) return rc;
+    s->g_ranks = (int)R;
+    s->g_words = W;
+    s->g_tiles = (W + YH_BLOCK - 1) / YH_BLOCK;
+    uint64_t* gmask = nullptr;
+    uint32_t *gtile = nullptr, *peer = nullptr;
+    std::vector<uint32_t> hp((size_t)R * 4);
+    for (uint32_t r = 0; r < R; ++r) {
+        hp[r * 4 + 0] = s->n_chunks;
+        hp[r * 4 + 1] = s->desc.id_base + r * (uint32_t)s->n;
+        hp[r * 4 + 2] = F;
+    }
+    hipError_t e = hipMalloc((void**)&gmask, (uint64_t)R * F * W * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(gmask, 0, (uint64_t)R * F * W * 8, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&gtile, (uint64_t)F * R * s->g_tiles * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&peer, (size_t)R * 16);
+    if (e == hipSuccess) e = hipMemcpy(peer, hp.data(), (size_t)R * 16, hipMemcpyHostToDevice);
+    for (uint32_t r = 0; r < R && e == hipSuccess; ++r)
+        e = hipMemcpy2DAsync(gmask + (uint64_t)r * F * W, (size_t)W * 8, s->last_mask, (size_t)s->n_chunks * 8, (size_t)s->n_chunks * 8, F,
+                             hipMemcpyDeviceToDevice, ctx->stream);
+    for (uint32_t f = 0; f < F && e == hipSuccess; ++f) {
+        const uint64_t cap = (uint64_t)R * W * 64;
+        if (s->gathered_cap[f] < cap) {
+            if (s->gathered[f]) (void)hipFree(s->gathered[f]);
+            s->gathered[f] = nullptr;
+            s->gathered_cap[f] = 0;
+            e = hipMalloc((void**)&s->gathered[f], cap * 4);
+            if (e == hipSuccess) s->gathered_cap[f] = cap;
+        }
+    }
+    int rc = YH_OK;
+    if (e == hipSuccess) {
+        // lend the buffers to the scene's gather fields for one expansion
+        s->gmask = gmask;
+        s->gtile = gtile;
+        s->d_peer = peer;
+        rc = gather_expand(s, F, ctx->stream);
+        if (rc == YH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, YH_ERR_HIP, "yh_gather_selftest: expansion failed");
+        s->gmask = nullptr;
+        s->gtile = nullptr;
+        s->d_peer = nullptr;
+        s->gathered_async = rc == YH_OK;
+    }
+    s->g_ranks = 0;
+    s->g_words = s->g_tiles = 0;
+    for (void* p : {(void*)gmask, (void*)gtile, (void*)peer})
+        if (p) (void)hipFree(p);
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? YH_ERR_OOM : YH_ERR_HIP, "yh_gather_selftest: %s", hipGetErrorString(e));
+    return rc;
+}
+
+// After a no-sync gather the host buffer holds running totals (ranks 0..r); turn them into per-rank counts once.
+static int finish_async_counts(yh_scene* s) {
+    if (!s->gathered_async) return YH_OK;
+    if (int rc = sync_scene(s)) return rc;
+    const int R = s->counts_ranks;
+    for (uint32_t f = 0; f < s->last_n_frusta; ++f) {
+        s->gathered_len[f] = s->h_all_counts[(R - 1) * YH_MAX_FRUSTA + f];
+        for (int r = R - 1; r > 0; --r) s->h_all_counts[r * YH_MAX_FRUSTA + f] -= s->h_all_counts[(r - 1) * YH_MAX_FRUSTA + f];
+    }
+    s->gathered_async = false;
     return YH_OK;
 }
 
@@ -1697,8 +1870,10 @@ extern "C" int yh_get_gathered_counts(yh_scene* s, uint32_t* all_counts) {
     if (!s || !all_counts) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_get_gathered_counts: NULL argument");
     if (!s->h_all_counts) return fail(s->ctx, YH_ERR_STATE, "yh_get_gathered_counts: no gather has run");
     if (int rc = sync_scene(s)) return rc;
+    if (int rc = finish_async_counts(s)) return rc;
     const uint32_t F = s->last_n_frusta;
-    for (int r = 0; r < s->ctx->n_ranks; ++r)
+    const int R = s->counts_ranks;
+    for (int r = 0; r < R; ++r)
         for (uint32_t f = 0; f < F; ++f) all_counts[r * F + f] = s->h_all_counts[r * YH_MAX_FRUSTA + f];
     return YH_OK;
 }
@@ -1706,15 +1881,7 @@ extern "C" int yh_get_gathered_counts(yh_scene* s, uint32_t* all_counts) {
 extern "C" int yh_get_gathered_draw_list(yh_scene* s, uint32_t frustum, uint32_t* out, uint64_t cap, uint64_t* written) {
     if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_get_gathered_draw_list: scene is NULL");
     ARG_TRY(s->ctx, frustum < s->last_n_frusta, "yh_get_gathered_draw_list: frustum index out of range");
-    if (s->gathered_async) {  // lengths become known on the host only now
-        if (int rc = sync_scene(s)) return rc;
-        for (uint32_t f = 0; f < s->last_n_frusta; ++f) {
-            uint64_t total = 0;
-            for (int r = 0; r < s->ctx->n_ranks; ++r) total += std::min<uint64_t>(s->h_all_counts[r * YH_MAX_FRUSTA + f], s->draw_cap);
-            s->gathered_len[f] = total;
-        }
-        s->gathered_async = false;
-    }
+    if (int rc = finish_async_counts(s)) return rc;  // lengths become known on the host only now
     const uint64_t c = s->gathered_len[frustum];
     if (written) *written = c;
     if (c > cap || (c && !out))
