@@ -14,7 +14,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CPU = os.path.join(ROOT, "oracle", "_ref", "flecs_harness")
-GPU = os.path.join(ROOT, "oracle", "_ref", "flecs_gpu_harness")
+# YFH_GPU_BIN: another build of the same harness, e.g. oracle/_ref/flecs_gpu_harness_asan (host-side sanitizers)
+GPU = os.environ.get("YFH_GPU_BIN") or os.path.join(ROOT, "oracle", "_ref", "flecs_gpu_harness")
 
 pytestmark = [
     pytest.mark.gpu,
