@@ -229,6 +229,8 @@ def main():
     if world_size > 1:
         import torch.distributed as dist
 
+        # one GPU per rank; a launcher that narrows each rank's visible devices to one leaves only index 0
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -315,8 +317,8 @@ def main():
         step()
     barrier()
     # timed region: K frames; only the dominant launch is bracketed by HIP events (on the library's stream)
-    # (an event record stalls the stream for ~3 us, so every 4th frame is sampled; at least 25 samples)
-    period = 4 if args.steps >= 100 else 1
+    # (an event record stalls the stream for ~3 us, so every 8th / 4th frame is sampled; at least 25 samples)
+    period = 8 if args.steps >= 200 else 4 if args.steps >= 100 else 1
     if not args.no_kernel_events:
         scene.set_kernel_timing(2 + dominant, period)
     t0 = time.perf_counter()
