@@ -27,6 +27,7 @@ struct yh_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t stream_c = nullptr;  // collectives of the no-host-sync gather (created by yh_comm_init)
+    hipStream_t stream_x = nullptr;  // expansion of the gathered words (beside the next all-gather)
     hipDeviceProp_t prop{};
     std::string err;
     // RCCL (optional)
@@ -120,14 +121,19 @@ struct yh_scene {
     uint32_t g_words = 0, g_tiles = 0, g_frusta = 0;  // longest shard's words per frustum row, its 256-word tiles
     uint32_t* d_peer = nullptr;       // [R][4] n_chunks, id_base, frusta, - of every rank (+ 4 words: this rank's own)
     std::vector<uint32_t> h_peer;
-    uint64_t* gmask = nullptr;        // [R][F][g_words] received words
+    uint64_t* gmask = nullptr;        // [2][R][F][g_words] received words, one set per frame parity
+    uint64_t gmask_set = 0;           // words per set
+    hipEvent_t ev_ag = nullptr;       // all-gather done (collective stream) -> expansion may start (expansion stream)
+    hipEvent_t ev_exp[2] = {nullptr, nullptr};  // expansion of set p done -> the all-gather after next may overwrite it
+    bool exp_busy[2] = {false, false};
+    uint32_t* h_all_counts_dev = nullptr;  // device address of the host-mapped totals
     uint64_t* send_pad = nullptr;     // [F][g_words] zero-padded copy of this rank's words (only if n_chunks < g_words)
     uint32_t* gtile = nullptr;        // [F][R][g_tiles]
     uint64_t* mask_alt = nullptr;     // second set of visibility words: frames alternate, so a frame's words stay
     uint32_t mparity = 0;             //   intact while the collective stream sends them (next frame writes the other set)
     uint64_t* last_mask = nullptr;    // the words the last culling frame wrote
     uint32_t last_mparity = 0;
-    hipEvent_t ev_frame = nullptr, ev_comm = nullptr, ev_mask[2] = {nullptr, nullptr};
+    hipEvent_t ev_frame = nullptr, ev_mask[2] = {nullptr, nullptr};
     bool mask_busy[2] = {false, false};  // ev_mask[p] must have passed before a frame writes word set p again
     bool gathered_async = false;  // h_all_counts holds running totals to be turned into counts after a sync
 };
@@ -199,7 +205,7 @@ extern "C" void yh_shutdown(yh_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     yh_comm_destroy(ctx);
-    for (hipStream_t st : {ctx->stream_c, ctx->stream}) {
+    for (hipStream_t st : {ctx->stream_x, ctx->stream_c, ctx->stream}) {
         if (!st) continue;
         (void)hipStreamSynchronize(st);
         (void)hipStreamDestroy(st);
@@ -224,6 +230,7 @@ extern "C" int yh_wait(yh_ctx* ctx) {
     if (!ctx) return fail(nullptr, YH_ERR_BAD_ARG, "yh_wait: ctx is NULL");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->stream_c) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
+    if (ctx->stream_x) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_x));
     return YH_OK;
 }
 
@@ -235,6 +242,7 @@ static void scene_free(yh_scene* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->ctx->stream_c) (void)hipStreamSynchronize(s->ctx->stream_c);
+    if (s->ctx->stream_x) (void)hipStreamSynchronize(s->ctx->stream_x);
     void* ptrs[] = {s->trs, s->lmat, s->world, s->parent, s->bounds, s->mesh_id, s->ldirty, s->wdirty, s->counts,
                     s->staging, s->d_all_counts, s->chg, s->chg_list};
     for (void* p : ptrs)
@@ -253,8 +261,7 @@ static void scene_free(yh_scene* s) {
     if (s->h_chg) (void)hipHostFree(s->h_chg);
     if (s->h_all_counts) (void)hipHostFree(s->h_all_counts);
     if (s->ev_frame) (void)hipEventDestroy(s->ev_frame);
-    if (s->ev_comm) (void)hipEventDestroy(s->ev_comm);
-    for (hipEvent_t e : s->ev_mask)
+    for (hipEvent_t e : {s->ev_mask[0], s->ev_mask[1], s->ev_exp[0], s->ev_exp[1], s->ev_ag})
         if (e) (void)hipEventDestroy(e);
     for (void* p : {(void*)s->d_peer, (void*)s->gmask, (void*)s->send_pad, (void*)s->gtile, (void*)s->mask_alt})
         if (p) (void)hipFree(p);
@@ -367,6 +374,7 @@ static int check_range(yh_scene* s, const char* who, uint64_t first, uint64_t co
 static int sync_scene(yh_scene* s) {
     HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
     if (s->ctx->stream_c) HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream_c));
+    if (s->ctx->stream_x) HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream_x));
     s->frame_pending = false;
     return YH_OK;
 }
@@ -1589,6 +1597,7 @@ extern "C" int yh_comm_init(yh_ctx* ctx, int n_ranks, int rank, const void* uniq
     memcpy(&id, unique_id, sizeof id);
     RCCL_TRY(ctx, g_rccl.CommInitRank(&ctx->comm, n_ranks, id, rank));
     if (!ctx->stream_c) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_c, hipStreamNonBlocking));
+    if (!ctx->stream_x) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_x, hipStreamNonBlocking));
     ctx->n_ranks = n_ranks;
     ctx->rank = rank;
     return YH_OK;
@@ -1599,6 +1608,7 @@ extern "C" void yh_comm_destroy(yh_ctx* ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->stream_c) (void)hipStreamSynchronize(ctx->stream_c);
+        if (ctx->stream_x) (void)hipStreamSynchronize(ctx->stream_x);
         g_rccl.CommDestroy(ctx->comm);
         ctx->comm = nullptr;
         ctx->n_ranks = 1;
@@ -1616,7 +1626,8 @@ static int ensure_all_counts(yh_scene* s, int R) {
     s->h_all_counts = nullptr;
     s->counts_cap = 0;
     HIP_TRY(ctx, hipMalloc((void**)&s->d_all_counts, (size_t)R * YH_MAX_FRUSTA * 4));
-    HIP_TRY(ctx, hipHostMalloc((void**)&s->h_all_counts, (size_t)R * YH_MAX_FRUSTA * 4, hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc((void**)&s->h_all_counts, (size_t)R * YH_MAX_FRUSTA * 4, hipHostMallocMapped));
+    HIP_TRY(ctx, hipHostGetDevicePointer((void**)&s->h_all_counts_dev, s->h_all_counts, 0));
     s->counts_cap = R;
     return YH_OK;
 }
@@ -1710,7 +1721,8 @@ static int gather_setup(yh_scene* s) {
     s->g_words = words;
     s->g_tiles = (words + YH_BLOCK - 1) / YH_BLOCK;
     s->g_frusta = F;
-    HIP_TRY(ctx, hipMalloc((void**)&s->gmask, (uint64_t)R * F * words * 8));
+    s->gmask_set = (uint64_t)R * F * words;
+    HIP_TRY(ctx, hipMalloc((void**)&s->gmask, 2 * s->gmask_set * 8));
     HIP_TRY(ctx, hipMalloc((void**)&s->gtile, (uint64_t)F * R * s->g_tiles * 4));
     if (s->n_chunks != words) {
         HIP_TRY(ctx, hipMalloc((void**)&s->send_pad, (uint64_t)F * words * 8));
@@ -1732,22 +1744,23 @@ static int gather_setup(yh_scene* s) {
     }
     if (int rc = ensure_all_counts(s, R)) return rc;
     HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_frame, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_comm, hipEventDisableTiming));
     for (hipEvent_t& e : s->ev_mask) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t& e : s->ev_exp) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_ag, hipEventDisableTiming));
     s->g_ranks = R;
     s->g_ready = true;
     return YH_OK;
 }
 
 // Expansion of the received words on stream sc (shared by the gather and its single-GPU self-test).
-static int gather_expand(yh_scene* s, uint32_t F, hipStream_t sc) {
+static int gather_expand(yh_scene* s, const uint64_t* gmask, uint32_t F, hipStream_t sc) {
     yh_ctx* ctx = s->ctx;
     GatherArgs g;
     memset(&g, 0, sizeof g);
-    g.gmask = s->gmask;
+    g.gmask = gmask;
     g.peer = s->d_peer;
     g.gtile = s->gtile;
-    g.cum = s->d_all_counts;
+    g.cum = s->h_all_counts_dev;  // host-mapped: the totals need no copy
     for (uint32_t f = 0; f < YH_MAX_FRUSTA; ++f) g.out[f] = s->gathered[f];
     g.words = s->g_words;
     g.n_tiles = s->g_tiles;
@@ -1757,7 +1770,6 @@ static int gather_expand(yh_scene* s, uint32_t F, hipStream_t sc) {
     hipLaunchKernelGGL(k_gather_count, grid, dim3(YH_BLOCK), 0, sc, g);
     hipLaunchKernelGGL(k_gather_expand, grid, dim3(YH_BLOCK), 0, sc, g);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(s->h_all_counts, s->d_all_counts, (size_t)s->g_ranks * YH_MAX_FRUSTA * 4, hipMemcpyDeviceToHost, sc));
     s->counts_ranks = s->g_ranks;
     return YH_OK;
 }
@@ -1781,11 +1793,22 @@ extern "C" int yh_allgather_draw_lists_async(yh_scene* s) {
                                       hipMemcpyDeviceToDevice, sc));
         send = s->send_pad;
     }
-    RCCL_TRY(ctx, g_rccl.AllGather(send, s->gmask, (size_t)F * W, /*ncclUint64*/ 5, ctx->comm, sc));
-    HIP_TRY(ctx, hipEventRecord(s->ev_mask[s->last_mparity], sc));
-    s->mask_busy[s->last_mparity] = true;
-    if (int rc = gather_expand(s, F, sc)) return rc;
-    HIP_TRY(ctx, hipEventRecord(s->ev_comm, sc));
+    const uint32_t p = s->last_mparity;
+    uint64_t* recv = s->gmask + (uint64_t)p * s->gmask_set;
+    if (s->exp_busy[p]) {  // the expansion two frames ago read this set of received words
+        HIP_TRY(ctx, hipStreamWaitEvent(sc, s->ev_exp[p], 0));
+        s->exp_busy[p] = false;
+    }
+    RCCL_TRY(ctx, g_rccl.AllGather(send, recv, (size_t)F * W, /*ncclUint64*/ 5, ctx->comm, sc));
+    HIP_TRY(ctx, hipEventRecord(s->ev_mask[p], sc));
+    s->mask_busy[p] = true;
+    // expansion on its own stream: the next frame's all-gather does not queue behind it
+    hipStream_t sx = ctx->stream_x;
+    HIP_TRY(ctx, hipEventRecord(s->ev_ag, sc));
+    HIP_TRY(ctx, hipStreamWaitEvent(sx, s->ev_ag, 0));
+    if (int rc = gather_expand(s, recv, F, sx)) return rc;
+    HIP_TRY(ctx, hipEventRecord(s->ev_exp[p], sx));
+    s->exp_busy[p] = true;
     s->gathered_async = true;
     s->frame_pending = true;
     return YH_OK;
@@ -1841,7 +1864,7 @@ extern "C" int yh_gather_selftest(yh_scene* s, uint32_t fake_ranks) {
         s->gmask = gmask;
         s->gtile = gtile;
         s->d_peer = peer;
-        rc = gather_expand(s, F, ctx->stream);
+        rc = gather_expand(s, gmask, F, ctx->stream);
         if (rc == YH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, YH_ERR_HIP, "yh_gather_selftest: expansion failed");
         s->gmask = nullptr;
         s->gtile = nullptr;
