@@ -56,7 +56,8 @@ def test_rccl_one_rank_allgather(oracle):
 
 
 def test_rccl_one_rank_allgather_without_host_sync(oracle):
-    """The pipelined exchange (collective stream, padded all-gather + packing kernel): same lists, frame after frame."""
+    """The pipelined exchange (visibility words all-gathered on the collective stream, expanded on a third stream):
+    same lists as the scene's own, frame after frame, with and without host syncs in between."""
     from yume_amd import Context, Scene, _lib
 
     n = 300_000
@@ -69,7 +70,8 @@ def test_rccl_one_rank_allgather_without_host_sync(oracle):
             s.upload_hierarchy(par, lo)
             s.fill_synthetic()
             flags = _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC
-            for k in range(4):  # back-to-back frames with different second frusta: each gather must see its own frame
+            for k in range(21):  # back-to-back frames with different second frusta: each gather must see its own frame
+                # (21 rounds of 1-2 frames: the ring of word sets wraps several times)
                 planes = np.concatenate([cams[0], cams[1 + k % 2]])
                 s.frame(planes, flags)
                 s.allgather_draw_lists_async()
@@ -81,6 +83,16 @@ def test_rccl_one_rank_allgather_without_host_sync(oracle):
                 assert gc.shape == (1, 2) and np.array_equal(gc[0], counts[:2])
                 for f in range(2):
                     assert np.array_equal(s.gathered_draw_list(f, gc[0, f]), s.draw_list(f))
+            # 50 frames and gathers enqueued without any host sync (the ring of word sets wraps six times)
+            for k in range(50):
+                planes = np.concatenate([cams[0], cams[1 + (k * 7 // 3) % 2]])
+                s.frame(planes, flags)
+                s.allgather_draw_lists_async()
+            counts, _ = s.counts()
+            gc = s.gathered_counts(2)
+            assert np.array_equal(gc[0], counts[:2])
+            for f in range(2):
+                assert np.array_equal(s.gathered_draw_list(f, gc[0, f]), s.draw_list(f))
             # the synchronous exchange still works afterwards
             assert np.array_equal(s.allgather_draw_lists()[0], counts[:2])
             assert np.array_equal(s.gathered_draw_list(1, counts[1]), s.draw_list(1))

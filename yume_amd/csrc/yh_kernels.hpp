@@ -630,7 +630,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_soa_to_aos68(const float* __restri
 // single ncclAllGather needs no counts first).  Every rank then expands all R masks itself, exactly as k_count /
 // k_expand do for its own: gmask = [rank][frustum][words] (rows zero-padded to the longest shard), output = the R
 // lists back to back in rank order with each rank's id_base added (ascending global ids when shards own ascending id
-// ranges).  grid = (tiles of 256 words, frusta, ranks).
+// ranges).  grid = (tiles of 64 or 256 words, frusta, ranks).
 struct GatherArgs {
     const uint64_t* gmask;    // [R][F][words]
     const uint32_t* peer;     // [R][4]: n_chunks, id_base, frusta, -
@@ -638,13 +638,14 @@ struct GatherArgs {
     uint32_t* cum;            // [R][YH_K_MAX_FRUSTA]: entries of ranks 0..r in frustum f (running total)
     uint32_t* out[YH_K_MAX_FRUSTA];
     uint32_t words, n_tiles, n_ranks, n_frusta;
+    uint32_t tile_words;  // words per tile: 64, or 256 for long rows (as k_expand)
 };
 
 __global__ __launch_bounds__(YH_BLOCK) void k_gather_count(const GatherArgs g) {
     __shared__ uint32_t s_red[4];
     const uint32_t t = blockIdx.x, f = blockIdx.y, r = blockIdx.z;
-    const uint32_t c = t * YH_BLOCK + threadIdx.x;
-    const uint64_t m = c < g.words ? g.gmask[((uint64_t)r * g.n_frusta + f) * g.words + c] : 0ull;
+    const uint32_t c = t * g.tile_words + threadIdx.x;
+    const uint64_t m = (threadIdx.x < g.tile_words && c < g.words) ? g.gmask[((uint64_t)r * g.n_frusta + f) * g.words + c] : 0ull;
     const uint32_t total = block_sum_256((uint32_t)__popcll(m), s_red);
     if (threadIdx.x == 0) g.gtile[((uint64_t)f * g.n_ranks + r) * g.n_tiles + t] = total;
 }
@@ -655,8 +656,8 @@ __global__ __launch_bounds__(YH_BLOCK) void k_gather_expand(const GatherArgs g) 
     __shared__ uint64_t s_mask[YH_BLOCK];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t t = blockIdx.x, f = blockIdx.y, r = blockIdx.z;
-    const uint32_t c0 = t * YH_BLOCK, c = c0 + tid;
-    const uint64_t m = c < g.words ? g.gmask[((uint64_t)r * g.n_frusta + f) * g.words + c] : 0ull;
+    const uint32_t c0 = t * g.tile_words, c = c0 + tid;
+    const uint64_t m = (tid < g.tile_words && c < g.words) ? g.gmask[((uint64_t)r * g.n_frusta + f) * g.words + c] : 0ull;
     const uint32_t pc = (uint32_t)__popcll(m);
     // base = entries of the ranks before this one and of this rank's tiles before this one
     const uint32_t* __restrict__ cnt = g.gtile + (uint64_t)f * g.n_ranks * g.n_tiles;
@@ -682,7 +683,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_gather_expand(const GatherArgs g) 
     if (own == 0) return;
     uint32_t* __restrict__ out = g.out[f];
     const uint32_t id_base = g.peer[r * 4 + 1];
-    const uint32_t n_words = min((uint32_t)YH_BLOCK, g.words - c0);
+    const uint32_t n_words = min(g.tile_words, g.words - c0);
 #pragma unroll 8
     for (uint32_t k = wv; k < n_words; k += 4) {
         const uint64_t mk = s_mask[k];  // wave-uniform

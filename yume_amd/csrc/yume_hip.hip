@@ -41,6 +41,8 @@ struct LevelGroup {
 };
 
 #define YH_TIMING_RING 2048
+#define YH_MASK_SETS 8u
+#define YH_MASK_HALF 4u
 
 struct yh_scene {
     yh_ctx* ctx = nullptr;
@@ -118,7 +120,7 @@ struct yh_scene {
     int g_ranks = 0;                  // ranks the buffers below were sized for
     int counts_cap = 0;               // ranks d_all_counts / h_all_counts have room for
     int counts_ranks = 0;             // ranks the host counts currently describe
-    uint32_t g_words = 0, g_tiles = 0, g_frusta = 0;  // longest shard's words per frustum row, its 256-word tiles
+    uint32_t g_words = 0, g_tiles = 0, g_frusta = 0, g_tile_words = 64;  // longest shard's words per frustum row, its tiles
     uint32_t* d_peer = nullptr;       // [R][4] n_chunks, id_base, frusta, - of every rank (+ 4 words: this rank's own)
     std::vector<uint32_t> h_peer;
     uint64_t* gmask = nullptr;        // [2][R][F][g_words] received words, one set per frame parity
@@ -126,15 +128,21 @@ struct yh_scene {
     hipEvent_t ev_ag = nullptr;       // all-gather done (collective stream) -> expansion may start (expansion stream)
     hipEvent_t ev_exp[2] = {nullptr, nullptr};  // expansion of set p done -> the all-gather after next may overwrite it
     bool exp_busy[2] = {false, false};
+    uint32_t gparity = 0;
     uint32_t* h_all_counts_dev = nullptr;  // device address of the host-mapped totals
     uint64_t* send_pad = nullptr;     // [F][g_words] zero-padded copy of this rank's words (only if n_chunks < g_words)
     uint32_t* gtile = nullptr;        // [F][R][g_tiles]
-    uint64_t* mask_alt = nullptr;     // second set of visibility words: frames alternate, so a frame's words stay
-    uint32_t mparity = 0;             //   intact while the collective stream sends them (next frame writes the other set)
+    // Ring of YH_MASK_SETS sets of visibility words (set 0 = vismask, the others in mask_alt): consecutive culling
+    // frames write consecutive sets, so a frame's words stay intact while the collective stream sends them.  The
+    // frames' stream waits for the exchange only at every YH_MASK_HALF-th frame, and then for an all-gather enqueued
+    // YH_MASK_HALF + 1 frames earlier (a wait packet costs the stream ~3.6 us even when already satisfied).
+    uint64_t* mask_alt = nullptr;
+    uint32_t mparity = 0;             // set the next culling frame writes
+    uint64_t mask_frame[YH_MASK_SETS] = {};  // frame number of the gather that last sent set p
     uint64_t* last_mask = nullptr;    // the words the last culling frame wrote
     uint32_t last_mparity = 0;
-    hipEvent_t ev_frame = nullptr, ev_mask[2] = {nullptr, nullptr};
-    bool mask_busy[2] = {false, false};  // ev_mask[p] must have passed before a frame writes word set p again
+    hipEvent_t ev_frame = nullptr, ev_mask[YH_MASK_SETS] = {};
+    bool mask_busy[YH_MASK_SETS] = {};  // ev_mask[p] must have passed before a frame writes word set p again
     bool gathered_async = false;  // h_all_counts holds running totals to be turned into counts after a sync
 };
 
@@ -184,13 +192,30 @@ extern "C" int yh_init(int device_id, yh_ctx** out) {
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipGetDeviceProperties(&c->prop, device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // The runtime multiplexes streams onto a few hardware queues (four here) in the order they are first used, and a
+    // wait packet in a shared queue holds back everything behind it: a gather stream that lands on the frames' queue
+    // serialises the exchange with the frames (measured: 50 -> 69 us per cfg2 frame).  All three streams are therefore
+    // created and touched here, back to back, so they occupy three consecutive queues whatever the host application
+    // or RCCL create later.  (Stream priorities are no way out: with the expansion below and the collectives above
+    // the frames' priority, a blocked wait packet starved the lower queue and the frames hung.)
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_x, hipStreamNonBlocking);
+    for (hipStream_t st : {c->stream, c->stream_c, c->stream_x}) {
+        hipEvent_t touch = nullptr;
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&touch, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(touch, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (touch) (void)hipEventDestroy(touch);
+    }
     if (e != hipSuccess) {
+        for (hipStream_t st : {c->stream_x, c->stream_c, c->stream})
+            if (st) (void)hipStreamDestroy(st);
         delete c;
         return fail(nullptr, YH_ERR_HIP, "yh_init: %s", hipGetErrorString(e));
     }
     if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
         std::string arch = c->prop.gcnArchName;
-        (void)hipStreamDestroy(c->stream);
+        for (hipStream_t st : {c->stream_x, c->stream_c, c->stream}) (void)hipStreamDestroy(st);
         delete c;
         return fail(nullptr, YH_ERR_UNSUPPORTED, "yh_init: device is %s; this library is built for gfx950 only",
                     arch.c_str());
@@ -261,7 +286,9 @@ static void scene_free(yh_scene* s) {
     if (s->h_chg) (void)hipHostFree(s->h_chg);
     if (s->h_all_counts) (void)hipHostFree(s->h_all_counts);
     if (s->ev_frame) (void)hipEventDestroy(s->ev_frame);
-    for (hipEvent_t e : {s->ev_mask[0], s->ev_mask[1], s->ev_exp[0], s->ev_exp[1], s->ev_ag})
+    for (hipEvent_t e : s->ev_mask)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {s->ev_exp[0], s->ev_exp[1], s->ev_ag})
         if (e) (void)hipEventDestroy(e);
     for (void* p : {(void*)s->d_peer, (void*)s->gmask, (void*)s->send_pad, (void*)s->gtile, (void*)s->mask_alt})
         if (p) (void)hipFree(p);
@@ -898,10 +925,19 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     a.wdirty = s->wdirty;
     a.bcount = s->counts + YH_MAX_FRUSTA * (1 + s->bparity);
     // visibility words: two sets once the no-sync gather is in use (the collective stream still sends the last frame's)
-    uint64_t* const words = (cull && s->mask_alt && s->mparity) ? s->mask_alt : s->vismask;
-    if (cull && s->mask_alt && s->mask_busy[s->mparity]) {
-        HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_mask[s->mparity], 0));
-        s->mask_busy[s->mparity] = false;
+    uint64_t* words = s->vismask;
+    if (cull && s->mask_alt) {
+        const uint32_t p = s->mparity;
+        if (p % YH_MASK_HALF == 0) {  // about to rewrite sets p .. p+HALF-1: the latest gather that sent one of them
+            int latest = -1;          // must be done (the collective stream runs in order, so the earlier ones are too)
+            for (uint32_t q = p; q < p + YH_MASK_HALF; ++q)
+                if (s->mask_busy[q]) {
+                    if (latest < 0 || s->mask_frame[q] > s->mask_frame[latest]) latest = (int)q;
+                    s->mask_busy[q] = false;
+                }
+            if (latest >= 0) HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_mask[latest], 0));
+        }
+        if (p) words = s->mask_alt + (uint64_t)(p - 1) * s->desc.n_frusta * s->n_chunks;
     }
     a.vismask = words;
     a.viscnt = s->viscnt;
@@ -1034,7 +1070,7 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         x.vismask = words;
         s->last_mask = words;
         s->last_mparity = s->mparity;
-        if (s->mask_alt) s->mparity ^= 1u;
+        if (s->mask_alt) s->mparity = (s->mparity + 1u) % YH_MASK_SETS;
         x.viscnt = s->viscnt;
         x.cnt_stride = s->cnt_stride;
         x.tilecnt = s->tilecnt;
@@ -1596,8 +1632,6 @@ extern "C" int yh_comm_init(yh_ctx* ctx, int n_ranks, int rank, const void* uniq
     yh_nccl_id id;
     memcpy(&id, unique_id, sizeof id);
     RCCL_TRY(ctx, g_rccl.CommInitRank(&ctx->comm, n_ranks, id, rank));
-    if (!ctx->stream_c) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_c, hipStreamNonBlocking));
-    if (!ctx->stream_x) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream_x, hipStreamNonBlocking));
     ctx->n_ranks = n_ranks;
     ctx->rank = rank;
     return YH_OK;
@@ -1719,7 +1753,8 @@ static int gather_setup(yh_scene* s) {
         words = std::max(words, s->h_peer[r * 4 + 0]);
     }
     s->g_words = words;
-    s->g_tiles = (words + YH_BLOCK - 1) / YH_BLOCK;
+    s->g_tile_words = words <= 32u * 4096u ? 64u : (uint32_t)YH_EXPAND_WORDS_MAX;
+    s->g_tiles = (words + s->g_tile_words - 1) / s->g_tile_words;
     s->g_frusta = F;
     s->gmask_set = (uint64_t)R * F * words;
     HIP_TRY(ctx, hipMalloc((void**)&s->gmask, 2 * s->gmask_set * 8));
@@ -1728,9 +1763,9 @@ static int gather_setup(yh_scene* s) {
         HIP_TRY(ctx, hipMalloc((void**)&s->send_pad, (uint64_t)F * words * 8));
         HIP_TRY(ctx, hipMemsetAsync(s->send_pad, 0, (uint64_t)F * words * 8, ctx->stream));
     }
-    HIP_TRY(ctx, hipMalloc((void**)&s->mask_alt, (uint64_t)F * s->n_chunks * 8));
+    HIP_TRY(ctx, hipMalloc((void**)&s->mask_alt, (uint64_t)(YH_MASK_SETS - 1) * F * s->n_chunks * 8));
     // (on the context's stream and waited for: the null stream's fills are not ordered with our non-blocking streams)
-    HIP_TRY(ctx, hipMemsetAsync(s->mask_alt, 0, (uint64_t)F * s->n_chunks * 8, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(s->mask_alt, 0, (uint64_t)(YH_MASK_SETS - 1) * F * s->n_chunks * 8, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (uint32_t f = 0; f < F; ++f) {
         const uint64_t cap = (uint64_t)R * words * 64;
@@ -1764,6 +1799,7 @@ static int gather_expand(yh_scene* s, const uint64_t* gmask, uint32_t F, hipStre
     for (uint32_t f = 0; f < YH_MAX_FRUSTA; ++f) g.out[f] = s->gathered[f];
     g.words = s->g_words;
     g.n_tiles = s->g_tiles;
+    g.tile_words = s->g_tile_words;
     g.n_ranks = (uint32_t)s->g_ranks;
     g.n_frusta = F;
     const dim3 grid(s->g_tiles, F, (uint32_t)s->g_ranks);
@@ -1793,22 +1829,25 @@ extern "C" int yh_allgather_draw_lists_async(yh_scene* s) {
                                       hipMemcpyDeviceToDevice, sc));
         send = s->send_pad;
     }
-    const uint32_t p = s->last_mparity;
-    uint64_t* recv = s->gmask + (uint64_t)p * s->gmask_set;
-    if (s->exp_busy[p]) {  // the expansion two frames ago read this set of received words
-        HIP_TRY(ctx, hipStreamWaitEvent(sc, s->ev_exp[p], 0));
-        s->exp_busy[p] = false;
+    const uint32_t p = s->last_mparity;  // the set of words the frame wrote
+    const uint32_t gp = s->gparity;      // the set of received words this gather fills
+    s->gparity ^= 1u;
+    uint64_t* recv = s->gmask + (uint64_t)gp * s->gmask_set;
+    if (s->exp_busy[gp]) {  // the expansion two gathers ago read this set of received words
+        HIP_TRY(ctx, hipStreamWaitEvent(sc, s->ev_exp[gp], 0));
+        s->exp_busy[gp] = false;
     }
     RCCL_TRY(ctx, g_rccl.AllGather(send, recv, (size_t)F * W, /*ncclUint64*/ 5, ctx->comm, sc));
     HIP_TRY(ctx, hipEventRecord(s->ev_mask[p], sc));
     s->mask_busy[p] = true;
+    s->mask_frame[p] = s->frames;
     // expansion on its own stream: the next frame's all-gather does not queue behind it
     hipStream_t sx = ctx->stream_x;
     HIP_TRY(ctx, hipEventRecord(s->ev_ag, sc));
     HIP_TRY(ctx, hipStreamWaitEvent(sx, s->ev_ag, 0));
     if (int rc = gather_expand(s, recv, F, sx)) return rc;
-    HIP_TRY(ctx, hipEventRecord(s->ev_exp[p], sx));
-    s->exp_busy[p] = true;
+    HIP_TRY(ctx, hipEventRecord(s->ev_exp[gp], sx));
+    s->exp_busy[gp] = true;
     s->gathered_async = true;
     s->frame_pending = true;
     return YH_OK;
@@ -1831,7 +1870,8 @@ extern "C" int yh_gather_selftest(yh_scene* s, uint32_t fake_ranks) {
     if (int rc = ensure_all_counts(s, (int)R)) return rc;
     s->g_ranks = (int)R;
     s->g_words = W;
-    s->g_tiles = (W + YH_BLOCK - 1) / YH_BLOCK;
+    s->g_tile_words = W <= 32u * 4096u ? 64u : (uint32_t)YH_EXPAND_WORDS_MAX;
+    s->g_tiles = (W + s->g_tile_words - 1) / s->g_tile_words;
     uint64_t* gmask = nullptr;
     uint32_t *gtile = nullptr, *peer = nullptr;
     std::vector<uint32_t> hp((size_t)R * 4);
