@@ -27,7 +27,6 @@ struct yh_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t stream_c = nullptr;  // collectives of the no-host-sync gather (created by yh_comm_init)
-    hipStream_t stream_x = nullptr;  // expansion of the gathered words (beside the next all-gather)
     hipDeviceProp_t prop{};
     std::string err;
     // RCCL (optional)
@@ -41,8 +40,8 @@ struct LevelGroup {
 };
 
 #define YH_TIMING_RING 2048
-#define YH_MASK_SETS 8u
-#define YH_MASK_HALF 4u
+#define YH_MASK_SETS 2u /* sets of visibility words frames rotate through while a gather is in flight */
+#define YH_MASK_HALF 1u /* the frames' stream checks on the gather every YH_MASK_HALF-th frame (8 / 4 measured the same) */
 
 struct yh_scene {
     yh_ctx* ctx = nullptr;
@@ -123,19 +122,13 @@ struct yh_scene {
     uint32_t g_words = 0, g_tiles = 0, g_frusta = 0, g_tile_words = 64;  // longest shard's words per frustum row, its tiles
     uint32_t* d_peer = nullptr;       // [R][4] n_chunks, id_base, frusta, - of every rank (+ 4 words: this rank's own)
     std::vector<uint32_t> h_peer;
-    uint64_t* gmask = nullptr;        // [2][R][F][g_words] received words, one set per frame parity
-    uint64_t gmask_set = 0;           // words per set
-    hipEvent_t ev_ag = nullptr;       // all-gather done (collective stream) -> expansion may start (expansion stream)
-    hipEvent_t ev_exp[2] = {nullptr, nullptr};  // expansion of set p done -> the all-gather after next may overwrite it
-    bool exp_busy[2] = {false, false};
-    uint32_t gparity = 0;
+    uint64_t* gmask = nullptr;        // [R][F][g_words] received words
     uint32_t* h_all_counts_dev = nullptr;  // device address of the host-mapped totals
     uint64_t* send_pad = nullptr;     // [F][g_words] zero-padded copy of this rank's words (only if n_chunks < g_words)
     uint32_t* gtile = nullptr;        // [F][R][g_tiles]
     // Ring of YH_MASK_SETS sets of visibility words (set 0 = vismask, the others in mask_alt): consecutive culling
-    // frames write consecutive sets, so a frame's words stay intact while the collective stream sends them.  The
-    // frames' stream waits for the exchange only at every YH_MASK_HALF-th frame, and then for an all-gather enqueued
-    // YH_MASK_HALF + 1 frames earlier (a wait packet costs the stream ~3.6 us even when already satisfied).
+    // frames write consecutive sets, so a frame's words stay intact while the collective stream sends them; before a
+    // set is rewritten the frames' stream waits for the all-gather that last sent it.
     uint64_t* mask_alt = nullptr;
     uint32_t mparity = 0;             // set the next culling frame writes
     uint64_t mask_frame[YH_MASK_SETS] = {};  // frame number of the gather that last sent set p
@@ -192,15 +185,12 @@ extern "C" int yh_init(int device_id, yh_ctx** out) {
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipGetDeviceProperties(&c->prop, device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    // The runtime multiplexes streams onto a few hardware queues (four here) in the order they are first used, and a
-    // wait packet in a shared queue holds back everything behind it: a gather stream that lands on the frames' queue
-    // serialises the exchange with the frames (measured: 50 -> 69 us per cfg2 frame).  All three streams are therefore
-    // created and touched here, back to back, so they occupy three consecutive queues whatever the host application
-    // or RCCL create later.  (Stream priorities are no way out: with the expansion below and the collectives above
-    // the frames' priority, a blocked wait packet starved the lower queue and the frames hung.)
+    // The collective stream of the no-sync gather is created and first used here, right after the frames' stream: the
+    // runtime multiplexes streams onto four hardware queues in the order they are first used, and a wait packet in a
+    // shared queue holds back everything behind it (a gather stream created after RCCL's own landed on the frames'
+    // queue and serialised the exchange with the frames: 50 -> 69 us per cfg2 frame).
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_x, hipStreamNonBlocking);
-    for (hipStream_t st : {c->stream, c->stream_c, c->stream_x}) {
+    for (hipStream_t st : {c->stream, c->stream_c}) {
         hipEvent_t touch = nullptr;
         if (e == hipSuccess) e = hipEventCreateWithFlags(&touch, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventRecord(touch, st);
@@ -208,14 +198,14 @@ extern "C" int yh_init(int device_id, yh_ctx** out) {
         if (touch) (void)hipEventDestroy(touch);
     }
     if (e != hipSuccess) {
-        for (hipStream_t st : {c->stream_x, c->stream_c, c->stream})
+        for (hipStream_t st : {c->stream_c, c->stream})
             if (st) (void)hipStreamDestroy(st);
         delete c;
         return fail(nullptr, YH_ERR_HIP, "yh_init: %s", hipGetErrorString(e));
     }
     if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
         std::string arch = c->prop.gcnArchName;
-        for (hipStream_t st : {c->stream_x, c->stream_c, c->stream}) (void)hipStreamDestroy(st);
+        for (hipStream_t st : {c->stream_c, c->stream}) (void)hipStreamDestroy(st);
         delete c;
         return fail(nullptr, YH_ERR_UNSUPPORTED, "yh_init: device is %s; this library is built for gfx950 only",
                     arch.c_str());
@@ -230,7 +220,7 @@ extern "C" void yh_shutdown(yh_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     yh_comm_destroy(ctx);
-    for (hipStream_t st : {ctx->stream_x, ctx->stream_c, ctx->stream}) {
+    for (hipStream_t st : {ctx->stream_c, ctx->stream}) {
         if (!st) continue;
         (void)hipStreamSynchronize(st);
         (void)hipStreamDestroy(st);
@@ -255,7 +245,6 @@ extern "C" int yh_wait(yh_ctx* ctx) {
     if (!ctx) return fail(nullptr, YH_ERR_BAD_ARG, "yh_wait: ctx is NULL");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->stream_c) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
-    if (ctx->stream_x) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_x));
     return YH_OK;
 }
 
@@ -267,7 +256,6 @@ static void scene_free(yh_scene* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->ctx->stream_c) (void)hipStreamSynchronize(s->ctx->stream_c);
-    if (s->ctx->stream_x) (void)hipStreamSynchronize(s->ctx->stream_x);
     void* ptrs[] = {s->trs, s->lmat, s->world, s->parent, s->bounds, s->mesh_id, s->ldirty, s->wdirty, s->counts,
                     s->staging, s->d_all_counts, s->chg, s->chg_list};
     for (void* p : ptrs)
@@ -287,8 +275,6 @@ static void scene_free(yh_scene* s) {
     if (s->h_all_counts) (void)hipHostFree(s->h_all_counts);
     if (s->ev_frame) (void)hipEventDestroy(s->ev_frame);
     for (hipEvent_t e : s->ev_mask)
-        if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {s->ev_exp[0], s->ev_exp[1], s->ev_ag})
         if (e) (void)hipEventDestroy(e);
     for (void* p : {(void*)s->d_peer, (void*)s->gmask, (void*)s->send_pad, (void*)s->gtile, (void*)s->mask_alt})
         if (p) (void)hipFree(p);
@@ -401,7 +387,6 @@ static int check_range(yh_scene* s, const char* who, uint64_t first, uint64_t co
 static int sync_scene(yh_scene* s) {
     HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
     if (s->ctx->stream_c) HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream_c));
-    if (s->ctx->stream_x) HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream_x));
     s->frame_pending = false;
     return YH_OK;
 }
@@ -1642,7 +1627,6 @@ extern "C" void yh_comm_destroy(yh_ctx* ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->stream_c) (void)hipStreamSynchronize(ctx->stream_c);
-        if (ctx->stream_x) (void)hipStreamSynchronize(ctx->stream_x);
         g_rccl.CommDestroy(ctx->comm);
         ctx->comm = nullptr;
         ctx->n_ranks = 1;
@@ -1756,8 +1740,7 @@ static int gather_setup(yh_scene* s) {
     s->g_tile_words = words <= 32u * 4096u ? 64u : (uint32_t)YH_EXPAND_WORDS_MAX;
     s->g_tiles = (words + s->g_tile_words - 1) / s->g_tile_words;
     s->g_frusta = F;
-    s->gmask_set = (uint64_t)R * F * words;
-    HIP_TRY(ctx, hipMalloc((void**)&s->gmask, 2 * s->gmask_set * 8));
+    HIP_TRY(ctx, hipMalloc((void**)&s->gmask, (uint64_t)R * F * words * 8));
     HIP_TRY(ctx, hipMalloc((void**)&s->gtile, (uint64_t)F * R * s->g_tiles * 4));
     if (s->n_chunks != words) {
         HIP_TRY(ctx, hipMalloc((void**)&s->send_pad, (uint64_t)F * words * 8));
@@ -1780,8 +1763,6 @@ static int gather_setup(yh_scene* s) {
     if (int rc = ensure_all_counts(s, R)) return rc;
     HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_frame, hipEventDisableTiming));
     for (hipEvent_t& e : s->ev_mask) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (hipEvent_t& e : s->ev_exp) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_ag, hipEventDisableTiming));
     s->g_ranks = R;
     s->g_ready = true;
     return YH_OK;
@@ -1830,24 +1811,13 @@ extern "C" int yh_allgather_draw_lists_async(yh_scene* s) {
         send = s->send_pad;
     }
     const uint32_t p = s->last_mparity;  // the set of words the frame wrote
-    const uint32_t gp = s->gparity;      // the set of received words this gather fills
-    s->gparity ^= 1u;
-    uint64_t* recv = s->gmask + (uint64_t)gp * s->gmask_set;
-    if (s->exp_busy[gp]) {  // the expansion two gathers ago read this set of received words
-        HIP_TRY(ctx, hipStreamWaitEvent(sc, s->ev_exp[gp], 0));
-        s->exp_busy[gp] = false;
-    }
-    RCCL_TRY(ctx, g_rccl.AllGather(send, recv, (size_t)F * W, /*ncclUint64*/ 5, ctx->comm, sc));
+    RCCL_TRY(ctx, g_rccl.AllGather(send, s->gmask, (size_t)F * W, /*ncclUint64*/ 5, ctx->comm, sc));
     HIP_TRY(ctx, hipEventRecord(s->ev_mask[p], sc));
     s->mask_busy[p] = true;
     s->mask_frame[p] = s->frames;
-    // expansion on its own stream: the next frame's all-gather does not queue behind it
-    hipStream_t sx = ctx->stream_x;
-    HIP_TRY(ctx, hipEventRecord(s->ev_ag, sc));
-    HIP_TRY(ctx, hipStreamWaitEvent(sx, s->ev_ag, 0));
-    if (int rc = gather_expand(s, recv, F, sx)) return rc;
-    HIP_TRY(ctx, hipEventRecord(s->ev_exp[gp], sx));
-    s->exp_busy[gp] = true;
+    // expansion behind it on the same stream (a third stream for it, so that the next all-gather need not queue
+    // behind this expansion, measured slower: 49-60 us per cfg2 frame against 46-48)
+    if (int rc = gather_expand(s, s->gmask, F, sc)) return rc;
     s->gathered_async = true;
     s->frame_pending = true;
     return YH_OK;
