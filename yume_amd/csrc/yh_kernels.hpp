@@ -724,11 +724,12 @@ __global__ __launch_bounds__(YH_BLOCK) void k_build_objects(const float* __restr
 // ---------------------------------------------------------------------------------------------------
 // Per-mesh bucketing of a draw list.  The reference's draw loop rebinds the vertex buffer
 // whenever "mesh != previous mesh" (RenderApi.zig:1434): handing it the visible entities grouped by mesh makes that
-// one bind per mesh.  A stable counting sort by mesh id: YH_BUCKET_WAVES waves own one contiguous slice of the
-// (ascending) list each; pass 1 histograms the slices, two small launches turn hist[mesh][wave] into output offsets,
-// pass 2 walks every slice again in order and scatters entity id, model matrix and draw record — so inside a
-// bucket the entities stay in ascending order.
-#define YH_BUCKET_WAVES 8192u
+// one bind per mesh.  A stable counting sort by mesh id: YH_BUCKET_SLICES workgroups own one contiguous slice of the
+// (ascending) list each; pass 1 histograms the slices, two small launches turn hist[mesh][slice] into output offsets,
+// pass 2 walks every slice again, 256 entries at a time: the tile is sorted by mesh inside LDS (ballot ranks per
+// wave, wave and mesh offsets by a scan) together with its model matrices, and leaves in bucket order, so entity id,
+// matrix and draw record go out in runs of consecutive positions — inside a bucket the entities stay ascending.
+#define YH_BUCKET_SLICES 4096u
 #define YH_BUCKET_MAX_MESHES 256u
 
 struct BucketArgs {
@@ -738,7 +739,7 @@ struct BucketArgs {
     uint32_t id_base;
     const uint32_t* mesh_id;
     uint32_t n_meshes;
-    uint32_t* hist;    // [n_meshes][YH_BUCKET_WAVES] counts, then (k_bucket_rows) exclusive offsets inside the row
+    uint32_t* hist;    // [n_meshes][YH_BUCKET_SLICES] counts, then (k_bucket_rows) exclusive offsets inside the row
     uint32_t* totals;  // [n_meshes]
     uint32_t* starts;  // [n_meshes] first output position of each bucket
     uint32_t* buckets; // [n_meshes] x {mesh, first, count}
@@ -750,42 +751,31 @@ struct BucketArgs {
     uint4* cmds;
 };
 
-__device__ __forceinline__ void bucket_slice(const BucketArgs& a, uint32_t gw, uint64_t& lo, uint64_t& hi) {
+__device__ __forceinline__ void bucket_slice(const BucketArgs& a, uint32_t slice, uint64_t& lo, uint64_t& hi) {
     uint64_t count = *a.count_ptr;
     if (count > a.cap) count = a.cap;
-    uint64_t per = (count + YH_BUCKET_WAVES - 1) / YH_BUCKET_WAVES;
-    per = (per + 63u) & ~(uint64_t)63u;
-    lo = (uint64_t)gw * per;
+    uint64_t per = (count + YH_BUCKET_SLICES - 1) / YH_BUCKET_SLICES;
+    per = (per + (YH_BLOCK - 1)) & ~(uint64_t)(YH_BLOCK - 1);
+    lo = (uint64_t)slice * per;
     hi = lo + per;
     if (lo > count) lo = count;
     if (hi > count) hi = count;
 }
 
 __global__ __launch_bounds__(YH_BLOCK) void k_bucket_hist(BucketArgs a) {
-    __shared__ uint32_t h[YH_BLOCK / 64][YH_BUCKET_MAX_MESHES];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t gw = blockIdx.x * (YH_BLOCK / 64) + wave;
-    for (uint32_t m = lane; m < a.n_meshes; m += 64) h[wave][m] = 0;
+    __shared__ uint32_t h[YH_BUCKET_MAX_MESHES];
+    for (uint32_t m = threadIdx.x; m < a.n_meshes; m += YH_BLOCK) h[m] = 0;
     __syncthreads();
     uint64_t lo, hi;
-    bucket_slice(a, gw, lo, hi);
-    for (uint64_t i = lo + lane; i < hi; i += 64) atomicAdd(&h[wave][a.mesh_id[a.list[i] - a.id_base]], 1u);
+    bucket_slice(a, blockIdx.x, lo, hi);
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += YH_BLOCK) atomicAdd(&h[a.mesh_id[a.list[i] - a.id_base]], 1u);
     __syncthreads();
-    for (uint32_t m = lane; m < a.n_meshes; m += 64) a.hist[(uint64_t)m * YH_BUCKET_WAVES + gw] = h[wave][m];
+    for (uint32_t m = threadIdx.x; m < a.n_meshes; m += YH_BLOCK) a.hist[(uint64_t)m * YH_BUCKET_SLICES + blockIdx.x] = h[m];
 }
 
-// One workgroup per mesh: exclusive scan of the row's YH_BUCKET_WAVES counts (32 per thread), total to totals[m].
-__global__ __launch_bounds__(YH_BLOCK) void k_bucket_rows(BucketArgs a) {
-    constexpr uint32_t PER = YH_BUCKET_WAVES / YH_BLOCK;
-    __shared__ uint32_t part[YH_BLOCK];
-    uint32_t* row = a.hist + (uint64_t)blockIdx.x * YH_BUCKET_WAVES + threadIdx.x * PER;
-    uint32_t v[PER], sum = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < PER; ++i) {
-        v[i] = row[i];
-        sum += v[i];
-    }
-    part[threadIdx.x] = sum;
+// Inclusive scan of one value per thread over the workgroup (256 threads), through LDS.
+__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t* part) {
+    part[threadIdx.x] = v;
     __syncthreads();
     for (uint32_t d = 1; d < YH_BLOCK; d <<= 1) {
         const uint32_t t = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
@@ -793,30 +783,38 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_rows(BucketArgs a) {
         part[threadIdx.x] += t;
         __syncthreads();
     }
-    uint32_t run = part[threadIdx.x] - sum;
+    return part[threadIdx.x];
+}
+
+// One workgroup per mesh: exclusive scan of the row's YH_BUCKET_SLICES counts (16 per thread), total to totals[m].
+__global__ __launch_bounds__(YH_BLOCK) void k_bucket_rows(BucketArgs a) {
+    constexpr uint32_t PER = YH_BUCKET_SLICES / YH_BLOCK;
+    __shared__ uint32_t part[YH_BLOCK];
+    uint32_t* row = a.hist + (uint64_t)blockIdx.x * YH_BUCKET_SLICES + threadIdx.x * PER;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < PER; ++i) {
+        v[i] = row[i];
+        sum += v[i];
+    }
+    const uint32_t inc = block_scan_256(sum, part);
+    uint32_t run = inc - sum;
 #pragma unroll
     for (uint32_t i = 0; i < PER; ++i) {
         row[i] = run;
         run += v[i];
     }
-    if (threadIdx.x == YH_BLOCK - 1) a.totals[blockIdx.x] = part[threadIdx.x];
+    if (threadIdx.x == YH_BLOCK - 1) a.totals[blockIdx.x] = inc;
 }
 
 // One workgroup: bucket starts = exclusive scan of the totals; the bucket table the renderer reads.
-__global__ __launch_bounds__(YH_BUCKET_MAX_MESHES) void k_bucket_starts(BucketArgs a) {
-    __shared__ uint32_t part[YH_BUCKET_MAX_MESHES];
+__global__ __launch_bounds__(YH_BLOCK) void k_bucket_starts(BucketArgs a) {
+    __shared__ uint32_t part[YH_BLOCK];
     const uint32_t m = threadIdx.x;
     const uint32_t total = m < a.n_meshes ? a.totals[m] : 0u;
-    part[m] = total;
-    __syncthreads();
-    for (uint32_t d = 1; d < YH_BUCKET_MAX_MESHES; d <<= 1) {
-        const uint32_t t = m >= d ? part[m - d] : 0u;
-        __syncthreads();
-        part[m] += t;
-        __syncthreads();
-    }
+    const uint32_t inc = block_scan_256(total, part);
     if (m < a.n_meshes) {
-        const uint32_t first = part[m] - total;
+        const uint32_t first = inc - total;
         a.starts[m] = first;
         a.buckets[3 * m + 0] = m;
         a.buckets[3 * m + 1] = first;
@@ -825,43 +823,73 @@ __global__ __launch_bounds__(YH_BUCKET_MAX_MESHES) void k_bucket_starts(BucketAr
 }
 
 __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
-    __shared__ uint32_t base_s[YH_BLOCK / 64][YH_BUCKET_MAX_MESHES];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t gw = blockIdx.x * (YH_BLOCK / 64) + wave;
-    volatile uint32_t* base = base_s[wave];  // private to the wave: its next output position per mesh
-    for (uint32_t m = lane; m < a.n_meshes; m += 64) base[m] = a.starts[m] + a.hist[(uint64_t)m * YH_BUCKET_WAVES + gw];
-    __syncthreads();
+    __shared__ uint32_t base[YH_BUCKET_MAX_MESHES];        // next output position of each bucket, for this slice
+    __shared__ uint32_t wcnt[4][YH_BUCKET_MAX_MESHES];     // entries of each mesh in each wave's 64, then wave offsets
+    __shared__ uint32_t lstart[YH_BUCKET_MAX_MESHES];      // first tile-local sorted index of each mesh
+    __shared__ uint32_t part[YH_BLOCK];
+    __shared__ uint32_t s_pos[YH_BLOCK], s_id[YH_BLOCK], s_vc[YH_BLOCK];  // the tile in bucket order
+    __shared__ uint32_t rows[YH_BLOCK * 17];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    for (uint32_t m = tid; m < a.n_meshes; m += YH_BLOCK) base[m] = a.starts[m] + a.hist[(uint64_t)m * YH_BUCKET_SLICES + blockIdx.x];
     uint64_t lo, hi;
-    bucket_slice(a, gw, lo, hi);
-    for (uint64_t i0 = lo; i0 < hi; i0 += 64) {  // wave-uniform trip count
-        const uint64_t i = i0 + lane;
-        const bool active = i < hi;
-        const uint32_t id = active ? a.list[i] : 0u;
+    bucket_slice(a, blockIdx.x, lo, hi);
+    for (uint64_t i0 = lo; i0 < hi; i0 += YH_BLOCK) {  // uniform trip count for the workgroup
+        const uint32_t n_tile = (uint32_t)((hi - i0 < YH_BLOCK) ? (hi - i0) : YH_BLOCK);
+        for (uint32_t m = tid; m < a.n_meshes; m += YH_BLOCK) wcnt[0][m] = wcnt[1][m] = wcnt[2][m] = wcnt[3][m] = 0;
+        __syncthreads();
+        const bool active = tid < n_tile;
+        const uint32_t id = active ? a.list[i0 + tid] : 0u;
         const uint32_t e = id - a.id_base;
         const uint32_t m = active ? a.mesh_id[e] : 0xFFFFFFFFu;
-        uint32_t pos = 0;
+        // rank among the wave's entries of the same mesh (entries are in list order lane by lane, wave by wave)
+        uint32_t rank = 0;
         uint64_t todo = __ballot(active);
-        while (todo) {  // one turn per distinct mesh among the 64 entries
+        while (todo) {  // one turn per distinct mesh among the wave's 64 entries
             const int leader = __ffsll((unsigned long long)todo) - 1;
             const uint32_t lm = __shfl(m, leader);
             const uint64_t same = __ballot(m == lm);
-            if (m == lm) pos = base[lm] + __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0u));
-            __builtin_amdgcn_wave_barrier();
-            if ((int)lane == leader) base[lm] = base[lm] + (uint32_t)__popcll(same);
-            __builtin_amdgcn_wave_barrier();
+            if (m == lm) rank = lane_rank(same);
+            if ((int)lane == leader) wcnt[wave][lm] = (uint32_t)__popcll(same);
             todo &= ~same;
         }
-        // (staging the rows through LDS so that four lanes write one 64-byte row together was measured 9 % slower)
+        float w[16];
         if (active) {
-            a.out_list[pos] = id;
-            a.cmds[pos] = make_uint4(a.vcount ? a.vcount[m] : 0u, 1u, 0u, a.batch_offset + pos);
             const uint64_t off = eoff<16>(e);
-            float4* dst = reinterpret_cast<float4*>(a.obj + (uint64_t)pos * 16);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                dst[c] = make_float4(lde(a.world, off, 4 * c), lde(a.world, off, 4 * c + 1), lde(a.world, off, 4 * c + 2),
-                                     lde(a.world, off, 4 * c + 3));
+            for (int q = 0; q < 16; ++q) w[q] = lde(a.world, off, q);
         }
+        __syncthreads();
+        // per mesh: counts of the four waves -> exclusive wave offsets, tile total -> tile-local start by a scan
+        uint32_t tile_cnt = 0;
+        if (tid < a.n_meshes) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const uint32_t c = wcnt[v][tid];
+                wcnt[v][tid] = tile_cnt;
+                tile_cnt += c;
+            }
+        }
+        const uint32_t inc = block_scan_256(tile_cnt, part);  // (ends with a barrier)
+        if (tid < a.n_meshes) lstart[tid] = inc - tile_cnt;
+        __syncthreads();
+        if (active) {
+            const uint32_t in_bucket = wcnt[wave][m] + rank;
+            const uint32_t ls = lstart[m] + in_bucket;
+            s_pos[ls] = base[m] + in_bucket;
+            s_id[ls] = id;
+            s_vc[ls] = a.vcount ? a.vcount[m] : 0u;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rows[ls * 17 + q] = __float_as_uint(w[q]);
+        }
+        __syncthreads();
+        if (tid < a.n_meshes) base[tid] += tile_cnt;
+        if (tid < n_tile) {
+            const uint32_t pos = s_pos[tid];
+            a.out_list[pos] = s_id[tid];
+            a.cmds[pos] = make_uint4(s_vc[tid], 1u, 0u, a.batch_offset + pos);
+        }
+        for (uint32_t i = tid; i < n_tile * 16u; i += YH_BLOCK) a.obj[(uint64_t)s_pos[i >> 4] * 16 + (i & 15u)] = rows[(i >> 4) * 17 + (i & 15u)];
+        __syncthreads();
     }
 }
 

@@ -83,7 +83,7 @@ struct yh_scene {
     // per-mesh buckets (yh_build_mesh_buckets): bucketed entity ids + bucket table per frustum, shared scratch
     uint32_t* blist[YH_MAX_FRUSTA] = {};
     uint32_t* bkt[YH_MAX_FRUSTA] = {};
-    uint32_t* bscratch = nullptr;     // hist [n_meshes][YH_BUCKET_WAVES] | totals | starts
+    uint32_t* bscratch = nullptr;     // hist [n_meshes][YH_BUCKET_SLICES] | totals | starts
     bool bucketed[YH_MAX_FRUSTA] = {};
     void* staging = nullptr;          // device staging for AoS68 import/export
     uint64_t staging_bytes = 0;
@@ -1178,7 +1178,7 @@ extern "C" int yh_build_mesh_buckets(yh_scene* s, uint32_t frustum, uint32_t bat
         HIP_TRY(ctx, hipMalloc((void**)&s->blist[frustum], s->draw_cap * 4));
         HIP_TRY(ctx, hipMalloc((void**)&s->bkt[frustum], (uint64_t)M * 12));
     }
-    if (!s->bscratch) HIP_TRY(ctx, hipMalloc((void**)&s->bscratch, ((uint64_t)M * YH_BUCKET_WAVES + 2 * M) * 4));
+    if (!s->bscratch) HIP_TRY(ctx, hipMalloc((void**)&s->bscratch, ((uint64_t)M * YH_BUCKET_SLICES + 2 * M) * 4));
     BucketArgs a{};
     a.list = s->draw[frustum];
     a.count_ptr = s->counts + frustum;
@@ -1187,7 +1187,7 @@ extern "C" int yh_build_mesh_buckets(yh_scene* s, uint32_t frustum, uint32_t bat
     a.mesh_id = s->mesh_id;
     a.n_meshes = s->n_meshes;
     a.hist = s->bscratch;
-    a.totals = s->bscratch + (uint64_t)M * YH_BUCKET_WAVES;
+    a.totals = s->bscratch + (uint64_t)M * YH_BUCKET_SLICES;
     a.starts = a.totals + M;
     a.buckets = s->bkt[frustum];
     a.world = s->world;
@@ -1196,10 +1196,10 @@ extern "C" int yh_build_mesh_buckets(yh_scene* s, uint32_t frustum, uint32_t bat
     a.out_list = s->blist[frustum];
     a.obj = s->obj[frustum];
     a.cmds = s->cmd[frustum];
-    const dim3 grid(YH_BUCKET_WAVES / (YH_BLOCK / 64));
+    const dim3 grid(YH_BUCKET_SLICES);
     hipLaunchKernelGGL(k_bucket_hist, grid, dim3(YH_BLOCK), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_bucket_rows, dim3(s->n_meshes), dim3(YH_BLOCK), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k_bucket_starts, dim3(1), dim3(YH_BUCKET_MAX_MESHES), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_bucket_starts, dim3(1), dim3(YH_BLOCK), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_bucket_scatter, grid, dim3(YH_BLOCK), 0, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
     s->frame_pending = true;
