@@ -316,11 +316,13 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # timed region: K frames; only the dominant launch is bracketed by HIP events (on the library's stream)
-    # (an event record stalls the stream for ~3 us, so every 8th / 4th frame is sampled; at least 25 samples)
+    # timed region: K frames; on every 8th / 4th frame (at least 25 samples) the transform launches carry a pair of
+    # HIP events each (hipExtLaunchKernelGGL on the library's stream: the dispatch's own start/end timestamps, the
+    # ones rocprofv3's kernel trace reports; nothing is added to the stream).  All transform launches of a sampled
+    # frame, not just the dominant one: a launch whose predecessor is not instrumented reads ~3 us long.
     period = 8 if args.steps >= 200 else 4 if args.steps >= 100 else 1
     if not args.no_kernel_events:
-        scene.set_kernel_timing(2 + dominant, period)
+        scene.set_kernel_timing(-1, period)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

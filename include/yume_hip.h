@@ -218,7 +218,9 @@ int yh_timings(yh_scene* s, yh_timing* out);
  * context's stream.  yh_scene_get_groups writes up to cap (first_level, last_level, first_entity,
  * end_entity) quadruples, one per launch; yh_scene_get_group_timings the mean device time per launch
  * since the previous call (at most 2048 launches are recorded between calls).  enable: 0 = off, 1 = every
- * launch plus the frame, 2 + i = only launch i of the frame (two event records per frame).               */
+ * launch plus the frame, 2 + i = only launch i of the frame, -1 = every transform launch of a TRS scene and nothing
+ * else.  A transform launch of a TRS scene carries its event pair itself (hipExtLaunchKernelGGL: the dispatch's
+ * own start/end timestamps, nothing added to the stream); everything else is bracketed by recorded events.   */
 int yh_scene_set_kernel_timing(yh_scene* s, int enable);
 /* Sample: record the events on every period-th frame only (an event record stalls the stream for ~3 us). */
 int yh_scene_set_kernel_timing_period(yh_scene* s, uint32_t period);

@@ -42,7 +42,8 @@ for d in sorted(glob.glob("gpurun_out/prof_*")):
         rf = bench.get("roofline") or {}
         lines += [f"bench under rocprof: {bench['value']} {bench['unit']}, {bench['ms_per_step']} ms/frame; dominant kernel "
                   f"`{rf.get('kernel')}` {rf.get('kernel_ms')} ms by HIP events, {rf.get('achieved')} GB/s algorithmic "
-                  f"(frac {rf.get('frac')})", ""]
+                  f"(frac {rf.get('frac')}).  With the profiler attached the launch's event pair reads a few µs above "
+                  f"the dispatch time below; in an un-profiled run it reads the same (bench_default_cfg2.json; DESIGN.md §5).", ""]
     lines += ["| kernel | calls | avg ns (kernel-trace) | FETCH_SIZE KiB | WRITE_SIZE KiB | traffic MB (2F+W) |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(stats[0])):
         k = r["Name"]

@@ -7,6 +7,7 @@
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -102,7 +103,7 @@ struct yh_scene {
     uint64_t frames = 0;
     uint32_t last_launches = 0;
     bool kernel_timing = false;
-    int timing_only = -1;  // >= 0: only this launch index gets events (and no frame events)
+    int timing_only = -1;  // >= 0: only this launch index gets events (and no frame events); -2: the transform launches
     uint32_t timing_period = 1;  // events on every timing_period-th frame only
     bool frame_timed = false;
     std::vector<hipEvent_t> kev;  // YH_TIMING_RING pairs, lazily created
@@ -831,24 +832,36 @@ extern "C" int yh_decompose(yh_scene* s, int which, float* const planes[10], uin
 }
 
 // ------------------------------------------------------------------------------------------------ frame
+// A pair of HIP events handed to the launch itself (hipExtLaunchKernelGGL) receives the dispatch's own start and end
+// timestamps — the ones rocprofv3's kernel trace reports — and puts no extra packet into the stream; events recorded
+// around a launch read 3-5 us more and stall the stream by as much.
+struct LaunchEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+#define YH_LAUNCH(kernel, grid, st, ev, ...)                                                                   \
+    do {                                                                                                       \
+        if ((ev).start) hipExtLaunchKernelGGL(kernel, grid, dim3(YH_BLOCK), 0, st, (ev).start, (ev).stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, dim3(YH_BLOCK), 0, st, __VA_ARGS__);                             \
+    } while (0)
+
 template <int BOUNDS>
-static void launch_trs(bool has_base, dim3 grid, hipStream_t st, const FrameArgs& a) {
-    if (has_base) hipLaunchKernelGGL((k_frame_trs<BOUNDS, true>), grid, dim3(YH_BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((k_frame_trs<BOUNDS, false>), grid, dim3(YH_BLOCK), 0, st, a);
+static void launch_trs(bool has_base, dim3 grid, hipStream_t st, LaunchEvents ev, const FrameArgs& a) {
+    if (has_base) YH_LAUNCH((k_frame_trs<BOUNDS, true>), grid, st, ev, a);
+    else YH_LAUNCH((k_frame_trs<BOUNDS, false>), grid, st, ev, a);
 }
 
 template <int BOUNDS, bool HAS_BASE>
-static void launch_chain_g(int G, dim3 grid, hipStream_t st, const FrameArgs& a) {
-    if (G <= 2) hipLaunchKernelGGL((k_frame_chain<2, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a);
-    else if (G <= 3) hipLaunchKernelGGL((k_frame_chain<3, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a);
-    else if (G <= 4) hipLaunchKernelGGL((k_frame_chain<4, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a);
-    else if (G <= 6) hipLaunchKernelGGL((k_frame_chain<6, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((k_frame_chain<8, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a);
+static void launch_chain_g(int G, dim3 grid, hipStream_t st, LaunchEvents ev, const FrameArgs& a) {
+    if (G <= 2) YH_LAUNCH((k_frame_chain<2, BOUNDS, HAS_BASE>), grid, st, ev, a);
+    else if (G <= 3) YH_LAUNCH((k_frame_chain<3, BOUNDS, HAS_BASE>), grid, st, ev, a);
+    else if (G <= 4) YH_LAUNCH((k_frame_chain<4, BOUNDS, HAS_BASE>), grid, st, ev, a);
+    else if (G <= 6) YH_LAUNCH((k_frame_chain<6, BOUNDS, HAS_BASE>), grid, st, ev, a);
+    else YH_LAUNCH((k_frame_chain<8, BOUNDS, HAS_BASE>), grid, st, ev, a);
 }
 template <int BOUNDS>
-static void launch_chain(int G, bool has_base, dim3 grid, hipStream_t st, const FrameArgs& a) {
-    if (has_base) launch_chain_g<BOUNDS, true>(G, grid, st, a);
-    else launch_chain_g<BOUNDS, false>(G, grid, st, a);
+static void launch_chain(int G, bool has_base, dim3 grid, hipStream_t st, LaunchEvents ev, const FrameArgs& a) {
+    if (has_base) launch_chain_g<BOUNDS, true>(G, grid, st, ev, a);
+    else launch_chain_g<BOUNDS, false>(G, grid, st, ev, a);
 }
 
 template <int BOUNDS, bool HAS_BASE>
@@ -938,7 +951,7 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         return dim3(cdiv((uint64_t)fa.end - (fa.begin & ~63u), YH_BLOCK));  // chunk-aligned 256-entity tiles
     };
 
-    const bool frame_events = s->kernel_timing && s->timing_only < 0 && (s->frames % s->timing_period == 0);
+    const bool frame_events = s->kernel_timing && s->timing_only == -1 && (s->frames % s->timing_period == 0);
     if (frame_events) HIP_TRY(ctx, hipEventRecord(s->ev0, st));
     uint32_t launches = 0;
     if (s->kernel_timing)
@@ -946,7 +959,7 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
 
     bool timing_this = false;
     auto time_begin = [&](uint32_t group) -> int {
-        timing_this = s->kernel_timing && s->kev_used < YH_TIMING_RING && (s->timing_only < 0 || (uint32_t)s->timing_only == group) &&
+        timing_this = s->kernel_timing && s->kev_used < YH_TIMING_RING && (s->timing_only == -1 || s->timing_only == (int)group) &&
                       (s->frames % s->timing_period == 0);
         if (timing_this) {
             s->kev_group[s->kev_used] = group;
@@ -961,6 +974,18 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         }
         return YH_OK;
     };
+    // single-kernel groups: the event pair rides on the launch instead
+    auto time_launch = [&](uint32_t group) -> LaunchEvents {
+        LaunchEvents ev;
+        if (s->kernel_timing && s->kev_used < YH_TIMING_RING && (s->timing_only < 0 || (uint32_t)s->timing_only == group) &&
+            (s->frames % s->timing_period == 0)) {
+            s->kev_group[s->kev_used] = group;
+            ev.start = s->kev[2 * s->kev_used];
+            ev.stop = s->kev[2 * s->kev_used + 1];
+            ++s->kev_used;
+        }
+        return ev;
+    };
 
     if (s->desc.local_kind == YH_LOCAL_TRS) {
         for (uint32_t gi = 0; gi < s->groups.size(); ++gi) {
@@ -969,23 +994,22 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
             a.end = s->level_offsets[g.hi + 1];
             if (a.end == a.begin) continue;
             const bool has_base = g.lo > 0;
-            if (int rc = time_begin(gi)) return rc;
+            const LaunchEvents ev = time_launch(gi);
             if (g.hi > g.lo) {
                 for (uint32_t j = 0; j < YH_MAX_GROUP; ++j)
                     a.lvl_begin[j] = (g.lo + 1 + j <= g.hi) ? s->level_offsets[g.lo + 1 + j] : 0xFFFFFFFFu;
                 const dim3 grid = grid_for(a);
                 const int G = (int)(g.hi - g.lo + 1);
-                if (bounds == 0) launch_chain<0>(G, has_base, grid, st, a);
-                else if (bounds == 1) launch_chain<1>(G, has_base, grid, st, a);
-                else launch_chain<2>(G, has_base, grid, st, a);
+                if (bounds == 0) launch_chain<0>(G, has_base, grid, st, ev, a);
+                else if (bounds == 1) launch_chain<1>(G, has_base, grid, st, ev, a);
+                else launch_chain<2>(G, has_base, grid, st, ev, a);
             } else {
                 const dim3 grid = grid_for(a);
-                if (bounds == 0) launch_trs<0>(has_base, grid, st, a);
-                else if (bounds == 1) launch_trs<1>(has_base, grid, st, a);
-                else launch_trs<2>(has_base, grid, st, a);
+                if (bounds == 0) launch_trs<0>(has_base, grid, st, ev, a);
+                else if (bounds == 1) launch_trs<1>(has_base, grid, st, ev, a);
+                else launch_trs<2>(has_base, grid, st, ev, a);
             }
             HIP_TRY(ctx, hipGetLastError());
-            if (int rc = time_end()) return rc;
             ++launches;
         }
     } else {
@@ -1284,7 +1308,7 @@ extern "C" int yh_scene_set_kernel_timing_period(yh_scene* s, uint32_t period) {
 extern "C" int yh_scene_set_kernel_timing(yh_scene* s, int enable) {
     if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_scene_set_kernel_timing: scene is NULL");
     s->kernel_timing = enable != 0;
-    s->timing_only = enable >= 2 ? enable - 2 : -1;
+    s->timing_only = enable >= 2 ? enable - 2 : enable < 0 ? -2 : -1;
     s->kev_used = 0;
     return YH_OK;
 }
