@@ -1,7 +1,7 @@
 // Host-side sanitizer run of the C ABI (include/yume_hip.h): this file and yume_amd/csrc/yume_hip.hip are compiled
 // into ONE executable with AddressSanitizer + UBSan on the host code only (make -C yume_amd/csrc asan_driver; the
 // device code is unchanged), and the calls below walk the library's host paths: scene set-up, uploads, frames of both
-// scene kinds, lists, consumers, buckets, change tracking, decompose, the gather self-test, error returns.
+// scene kinds, lists, consumers, buckets, change tracking, decompose, the gather self-test, a one-rank RCCL gather, error returns.
 // Results are only sanity-checked here (the parity tests own correctness); what matters is that the sanitizers stay
 // silent.  Run on a GPU box:  ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 ./tools/bin/abi_asan_driver
 #include <cmath>
@@ -231,6 +231,48 @@ int main() {
         CK(yh_get_changed_count(s, &changed));
         EXPECT(changed == n);
         yh_scene_destroy(s);
+    }
+    // ---- one-rank communicator: both forms of the draw-list gather ----
+    {
+        unsigned char id[YH_UNIQUE_ID_BYTES];
+        CK(yh_comm_unique_id(id));
+        CK(yh_comm_init(ctx, 1, 0, id));
+        const uint32_t n = 200003, levels = 3;
+        std::vector<uint32_t> lo, parent;
+        tree(n, levels, lo, parent);
+        yh_scene_desc d;
+        memset(&d, 0, sizeof d);
+        d.n_entities = n;
+        d.n_levels = levels;
+        d.n_frusta = 2;
+        d.local_kind = YH_LOCAL_TRS;
+        d.bounds_kind = YH_BOUNDS_PER_ENTITY;
+        d.id_base = 77;
+        yh_scene* s = nullptr;
+        CK(yh_scene_create(ctx, &d, &s));
+        CK(yh_upload_hierarchy(s, parent.data(), lo.data()));
+        yh_synth_desc sd;
+        memset(&sd, 0, sizeof sd);
+        sd.seed = 3;
+        CK(yh_scene_fill_synthetic(s, &sd));
+        for (int k = 0; k < 9; ++k) {
+            CK(yh_frame(s, planes, 1 + (k & 1), YH_FRAME_ALL_DIRTY | YH_FRAME_ASYNC));
+            CK(yh_allgather_draw_lists_async(s));
+        }
+        uint32_t counts[8], bc[8], gc[2];
+        CK(yh_get_gathered_counts(s, gc));
+        CK(yh_get_counts(s, counts, bc));
+        EXPECT(gc[0] == counts[0] && counts[0] > 0);
+        std::vector<uint32_t> own(counts[0]), got(counts[0]);
+        uint64_t wr = 0;
+        CK(yh_get_draw_list(s, 0, own.data(), own.size(), &wr));
+        CK(yh_get_gathered_draw_list(s, 0, got.data(), got.size(), &wr));
+        EXPECT(wr == counts[0] && memcmp(own.data(), got.data(), own.size() * 4) == 0);
+        CK(yh_allgather_draw_lists(s, gc));
+        EXPECT(gc[0] == counts[0]);
+        EXPECT(yh_get_gathered_draw_list(s, 0, got.data(), 1, &wr) == YH_ERR_CAPACITY);
+        yh_scene_destroy(s);
+        yh_comm_destroy(ctx);
     }
     yh_shutdown(ctx);
     printf("abi_asan_driver: ok\n");
