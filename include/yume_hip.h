@@ -84,7 +84,9 @@ typedef struct yh_scene_desc {
 #define YH_FRAME_ALL_DIRTY   0x1u /* every LocalTransform is dirty: forward branch everywhere (benchmark mode;
                                      the only mode of YH_LOCAL_TRS scenes)                                   */
 #define YH_FRAME_NO_CULL     0x2u /* skip stage 3 */
-#define YH_FRAME_ASYNC       0x4u /* enqueue only; yh_wait() or any yh_get_ / yh_download_ call synchronises */
+#define YH_FRAME_ASYNC       0x4u /* enqueue only; yh_wait() or any yh_get_ / yh_download_ call synchronises.  Small TRS
+                                     scenes (<= ~1M entities) leave the frame's list expansion to the next frame's first
+                                     launch, or to the first call that reads the lists: results are the same */
 #define YH_FRAME_ORDERED     0x8u /* accepted, no effect: draw lists are ALWAYS in ascending entity order        */
 
 typedef struct yh_timing {

@@ -371,6 +371,49 @@ def test_mesh_buckets_need_a_mesh_table(ctx, oracle):
         assert e.value.code == _lib.YH_ERR_STATE
 
 
+@pytest.mark.parametrize("n,levels", [(300_000, 6), (5000, 1), (1_000_000, 8)])
+def test_async_frames_defer_their_expansion_and_give_the_same_lists(ctx, oracle, n, levels):
+    """YH_FRAME_ASYNC frames of small TRS scenes leave their list expansion to the next frame's first launch (or to the
+    first reader).  Whatever reads next — counts, a list, the object-data consumer, a plain yh_wait — has to see
+    exactly the frame's own lists, boundary counts included, with the frusta changing from frame to frame."""
+    from yume_amd import _lib
+
+    lo, par, trs, bounds = make_scene(oracle, n, levels)
+    n = trs.shape[1]
+    cams = [oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()[:1], oracle.cascade_planes()[1:2],
+            oracle.cascade_planes()[2:3]]
+    exp_w = oracle.frame_trs(trs, par, lo, n_threads=8)
+    expect = {}
+
+    def expected(k):
+        if k not in expect:
+            expect[k] = oracle.cull(exp_w, bounds, np.concatenate(cams[: 1 + k]), n_threads=8)
+        return expect[k]
+
+    flags = _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC
+    with gpu_scene(ctx, lo, par, trs, bounds, 4) as s:
+        readers = ["counts", "list", "object", "wait", "sync-frame"]
+        for rnd in range(10):
+            nf = 1 + rnd % 4
+            for j in range(1 + rnd % 3):  # one to three frames back to back, then the one that is checked
+                s.frame(np.concatenate(cams[: 1 + (rnd + j) % 4]), flags)
+            s.frame(np.concatenate(cams[:nf]), flags)
+            vis, bnd = expected(nf - 1)
+            how = readers[rnd % len(readers)]
+            if how == "object":
+                m, c = s.object_data(nf - 1)
+                lst = np.flatnonzero(vis[nf - 1]).astype(np.uint32)
+                assert_same_values(m, exp_w["m"][lst], "object data behind a deferred expansion")
+            elif how == "wait":
+                ctx.wait()
+            elif how == "sync-frame":
+                s.frame(np.concatenate(cams[:nf]), _lib.YH_FRAME_ALL_DIRTY)
+            counts, bcounts = s.counts()
+            for f in range(nf):
+                assert counts[f] == np.count_nonzero(vis[f]) and bcounts[f] == np.count_nonzero(bnd[f]), (rnd, how, f)
+                assert np.array_equal(s.draw_list(f), np.flatnonzero(vis[f]).astype(np.uint32)), (rnd, how, f)
+
+
 def test_boundary_cases_are_counted(ctx, oracle):
     """Entities placed exactly on / within 1e-5 of a plane are reported in boundary_counts."""
     from yume_amd import Scene

@@ -141,6 +141,110 @@ __device__ __forceinline__ void load_inputs(const FrameArgs& a, uint32_t e, TrsI
     in.pidx = NEED_PARENT ? a.parent[e] : 0u;
 }
 
+// ---- stage 3 back end, part 2: prefix sums + expansion into ordered draw lists -----------------------------
+// (Defined ahead of the frame kernels: the first launch of a small scene's frame can carry the previous frame's
+// expansion, see k_frame_*_x.)  An expand tile is `words` visibility words (32, 64 = 4096 entities, or 256 for scenes
+// beyond 8M entities).
+// k_count reduces every tile to its visible count; k_expand gives one workgroup to each (tile, frustum): its base
+// is the sum of the tile counts before it (read redundantly: a few thousand L2-resident words, cheaper than a
+// dependent scan launch), the tile's words are prefix-summed through LDS and the 4 waves expand them
+// round-robin, one word per step: lane l emits entity chunk*64+l at rank mbcnt(word).  Ascending entity order,
+// coalesced stores, no atomics.  Scenes of at most YH_SELF_COUNT_TILES tiles (2M entities) skip k_count: the frame
+// kernels store each word's popcount as a byte next to it, and every expand workgroup adds up the bytes before its
+// tile itself (16 per load, v_dot4: at most 32 KiB of L2-resident bytes) — one dependent launch less per frame.
+#define YH_EXPAND_WORDS_MAX 256
+#define YH_SELF_COUNT_TILES 512
+
+struct ExpandArgs {
+    const uint64_t* vismask;
+    const uint8_t* viscnt;  // [frustum][cnt_stride] popcounts of the words, written with them
+    uint32_t cnt_stride;
+    uint32_t* tilecnt;      // [frustum][n_tiles]
+    uint32_t* counts;       // device totals [frustum] (input of the RCCL all-gather)
+    uint32_t* bcount_cur;   // boundary counters accumulated by this frame's launches
+    uint32_t* bcount_next;  // the set of the frame after next: zeroed here (the next frame's launches may be running)
+    uint32_t* host_counts;  // host-mapped: [frustum] totals, [8 + frustum] boundary counts
+    uint32_t* draw[YH_K_MAX_FRUSTA];
+    uint64_t draw_cap;
+    uint32_t n_chunks, n_tiles, id_base, self_count;
+    uint32_t words;  // visibility words per tile: 32, 64 or 256
+    uint32_t fuse_blocks;  // k_frame_*_x: the launch's first fuse_blocks workgroups expand these (the previous frame's) words
+};
+
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* s_red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const uint32_t r = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t t, const uint32_t f) {
+    __shared__ uint32_t s_red[4];
+    __shared__ uint32_t s_off[YH_BLOCK];
+    __shared__ uint64_t s_mask[YH_BLOCK];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint64_t* __restrict__ masks = x.vismask + (uint64_t)f * x.n_chunks;
+    const uint32_t c0 = t * x.words;
+    const uint32_t c = c0 + tid;
+    const uint64_t m = (tid < x.words && c < x.n_chunks) ? masks[c] : 0ull;
+    const uint32_t pc = (uint32_t)__popcll(m);
+    // base = visible entities in the tiles before this one
+    uint32_t part = 0;
+    if (x.self_count) {  // 16 byte-counts per load; c0 is a multiple of 64
+        const uint4* __restrict__ c16 = reinterpret_cast<const uint4*>(x.viscnt + (uint64_t)f * x.cnt_stride);
+        for (uint32_t i = tid; i < c0 / 16; i += YH_BLOCK) {
+            const uint4 v = c16[i];
+            part = __builtin_amdgcn_udot4(v.x, 0x01010101u, part, false);
+            part = __builtin_amdgcn_udot4(v.y, 0x01010101u, part, false);
+            part = __builtin_amdgcn_udot4(v.z, 0x01010101u, part, false);
+            part = __builtin_amdgcn_udot4(v.w, 0x01010101u, part, false);
+        }
+    } else {
+        const uint32_t* __restrict__ cnt = x.tilecnt + (uint64_t)f * x.n_tiles;
+        for (uint32_t i = tid; i < t; i += YH_BLOCK) part += cnt[i];
+    }
+    const uint32_t base = block_sum_256(part, s_red);
+    // exclusive scan of the 256 popcounts
+    uint32_t inc = pc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o);
+        if ((int)lane >= o) inc += v;
+    }
+    if (lane == 63) s_red[wv] = inc;
+    s_mask[tid] = m;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < wv; ++w) wbase += s_red[w];
+    s_off[tid] = wbase + inc - pc;
+    const uint32_t own = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    if (tid == 0) {
+        if (t == 0 && f == 0)  // all of them: the frame that uses this set next may cull more frusta than this one
+            for (uint32_t q = 0; q < YH_K_MAX_FRUSTA; ++q) x.bcount_next[q] = 0;
+        if (t + 1 == x.n_tiles) {  // totals of this frustum, to the device (all-gather) and straight to the host
+            x.counts[f] = base + own;
+            x.host_counts[f] = base + own;
+            x.host_counts[YH_K_MAX_FRUSTA + f] = x.bcount_cur[f];
+        }
+    }
+    if (own == 0) return;
+    uint32_t* __restrict__ out = x.draw[f];
+    const uint32_t n_words = min(x.words, x.n_chunks - c0);
+#pragma unroll 8
+    for (uint32_t k = wv; k < n_words; k += 4) {
+        const uint64_t mk = s_mask[k];  // wave-uniform
+        if (mk) {
+            const uint64_t pos = (uint64_t)base + s_off[k] + lane_rank(mk);
+            if (((mk >> lane) & 1ull) && pos < x.draw_cap) out[pos] = ((c0 + k) << 6) + lane + x.id_base;
+        }
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------------
 // Fused frame kernel, TRS locals, every LocalTransform dirty (forward branch of
 // TransformSyncSystem.zig:67-68 on every row), ONE level per launch:
@@ -150,10 +254,10 @@ __device__ __forceinline__ void load_inputs(const FrameArgs& a, uint32_t e, TrsI
 // 1 per-entity planes, 2 mesh table.  HAS_BASE: the level is > 0 (its entities have stored parents), else the
 // parent is the scene root.
 template <int BOUNDS, bool HAS_BASE>
-__global__ __launch_bounds__(YH_BLOCK) void k_frame_trs(const FrameArgs a) {
+__device__ __forceinline__ void frame_trs_tile(const FrameArgs& a, const uint32_t tile) {
     const uint32_t tid = threadIdx.x;
     // chunk-aligned mapping: every wave covers exactly one 64-entity chunk of the arrays
-    const uint64_t e64 = (uint64_t)(a.begin & ~63u) + (uint64_t)blockIdx.x * YH_BLOCK + tid;
+    const uint64_t e64 = (uint64_t)(a.begin & ~63u) + (uint64_t)tile * YH_BLOCK + tid;
     if (e64 - (tid & 63u) >= a.end) return;  // this wave's chunk starts past the end (wave-uniform)
     const bool valid = e64 >= a.begin && e64 < a.end;
     // lanes outside [begin, end) redo a valid entity of the launch and store nothing
@@ -185,9 +289,9 @@ __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs(const FrameArgs a) {
 // and a dependent walk up the parent chain for G-1 fewer dependent launches.  Best for shallow groups of
 // small levels (the top of a tree), where a launch boundary costs more than the level's own traffic.
 template <int G, int BOUNDS, bool HAS_BASE>
-__global__ __launch_bounds__(YH_BLOCK) void k_frame_chain(const FrameArgs a) {
+__device__ __forceinline__ void frame_chain_tile(const FrameArgs& a, const uint32_t tile) {
     const uint32_t tid = threadIdx.x;
-    const uint64_t e64 = (uint64_t)(a.begin & ~63u) + (uint64_t)blockIdx.x * YH_BLOCK + tid;
+    const uint64_t e64 = (uint64_t)(a.begin & ~63u) + (uint64_t)tile * YH_BLOCK + tid;
     if (e64 - (tid & 63u) >= a.end) return;  // this wave's chunk starts past the end (wave-uniform)
     const bool valid = e64 >= a.begin && e64 < a.end;
     const uint32_t e = e64 < a.begin ? a.begin : (e64 < a.end ? (uint32_t)e64 : a.end - 1u);
@@ -232,6 +336,37 @@ __global__ __launch_bounds__(YH_BLOCK) void k_frame_chain(const FrameArgs a) {
         if (!valid) vmask = bmask = 0;
         publish_visible(a, (uint32_t)(e64 >> 6), e64 - (tid & 63u) < a.begin, vmask, bmask);
     }
+}
+
+template <int BOUNDS, bool HAS_BASE>
+__global__ __launch_bounds__(YH_BLOCK) void k_frame_trs(const FrameArgs a) {
+    frame_trs_tile<BOUNDS, HAS_BASE>(a, blockIdx.x);
+}
+template <int G, int BOUNDS, bool HAS_BASE>
+__global__ __launch_bounds__(YH_BLOCK) void k_frame_chain(const FrameArgs a) {
+    frame_chain_tile<G, BOUNDS, HAS_BASE>(a, blockIdx.x);
+}
+// The first launch of a frame (levels from 0: no stored base parent) with the PREVIOUS frame's expansion on board: the
+// launch's first x.fuse_blocks workgroups run expand_tile on the previous frame's words, the others are the frame's
+// own tiles.  For scenes of up to ~1M entities a frame is a handful of 5-20 us launches and the expansion's own
+// dependent launch is a tenth of it (cfg2: 41.1 -> 37.5 us per frame); the two halves touch different word sets,
+// count bytes and boundary counters (the host alternates them).  Larger scenes keep the separate k_expand launch
+// (measured: nothing to gain, and the extra LDS and arguments cost the big kernels 1-2 %).
+template <int BOUNDS>
+__global__ __launch_bounds__(YH_BLOCK) void k_frame_trs_x(const FrameArgs a, const ExpandArgs x) {
+    if (blockIdx.x < x.fuse_blocks) {
+        expand_tile(x, blockIdx.x % x.n_tiles, blockIdx.x / x.n_tiles);
+        return;
+    }
+    frame_trs_tile<BOUNDS, false>(a, blockIdx.x - x.fuse_blocks);
+}
+template <int G, int BOUNDS>
+__global__ __launch_bounds__(YH_BLOCK) void k_frame_chain_x(const FrameArgs a, const ExpandArgs x) {
+    if (blockIdx.x < x.fuse_blocks) {
+        expand_tile(x, blockIdx.x % x.n_tiles, blockIdx.x / x.n_tiles);
+        return;
+    }
+    frame_chain_tile<G, BOUNDS, false>(a, blockIdx.x - x.fuse_blocks);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -383,43 +518,6 @@ __global__ __launch_bounds__(YH_BLOCK) void k_chain_mat4(const FrameArgs a, cons
     if (BOUNDS != 0) publish_visible(a, (uint32_t)(e64 >> 6), e64 - (tid & 63u) < a.begin, vmask, bmask);
 }
 
-// ---- stage 3 back end, part 2: prefix sums + expansion into ordered draw lists -----------------------------
-// An expand tile is `words` visibility words (64 = 4096 entities, or 256 for scenes beyond 16M entities).
-// k_count reduces every tile to its visible count; k_expand gives one workgroup to each (tile, frustum): its base
-// is the sum of the tile counts before it (read redundantly: a few thousand L2-resident words, cheaper than a
-// dependent scan launch), the tile's words are prefix-summed through LDS and the 4 waves expand them
-// round-robin, one word per step: lane l emits entity chunk*64+l at rank mbcnt(word).  Ascending entity order,
-// coalesced stores, no atomics.  Scenes of at most YH_SELF_COUNT_TILES tiles (2M entities) skip k_count: the frame
-// kernels store each word's popcount as a byte next to it, and every expand workgroup adds up the bytes before its
-// tile itself (16 per load, v_dot4: at most 32 KiB of L2-resident bytes) — one dependent launch less per frame.
-#define YH_EXPAND_WORDS_MAX 256
-#define YH_SELF_COUNT_TILES 512
-
-struct ExpandArgs {
-    const uint64_t* vismask;
-    const uint8_t* viscnt;  // [frustum][cnt_stride] popcounts of the words, written with them
-    uint32_t cnt_stride;
-    uint32_t* tilecnt;      // [frustum][n_tiles]
-    uint32_t* counts;       // device totals [frustum] (input of the RCCL all-gather)
-    uint32_t* bcount_cur;   // boundary counters accumulated by this frame's launches
-    uint32_t* bcount_next;  // the other parity: zeroed here for the next frame
-    uint32_t* host_counts;  // host-mapped: [frustum] totals, [8 + frustum] boundary counts
-    uint32_t* draw[YH_K_MAX_FRUSTA];
-    uint64_t draw_cap;
-    uint32_t n_chunks, n_tiles, id_base, self_count;
-    uint32_t words;  // visibility words per tile: 64 or 256
-};
-
-__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* s_red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const uint32_t r = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    __syncthreads();
-    return r;
-}
-
 __global__ __launch_bounds__(YH_BLOCK) void k_count(const ExpandArgs x) {
     __shared__ uint32_t s_red[4];
     const uint32_t t = blockIdx.x, f = blockIdx.y;
@@ -429,68 +527,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_count(const ExpandArgs x) {
     if (threadIdx.x == 0) x.tilecnt[f * x.n_tiles + t] = total;
 }
 
-__global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) {
-    __shared__ uint32_t s_red[4];
-    __shared__ uint32_t s_off[YH_BLOCK];
-    __shared__ uint64_t s_mask[YH_BLOCK];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const uint32_t t = blockIdx.x, f = blockIdx.y;
-    const uint64_t* __restrict__ masks = x.vismask + (uint64_t)f * x.n_chunks;
-    const uint32_t c0 = t * x.words;
-    const uint32_t c = c0 + tid;
-    const uint64_t m = (tid < x.words && c < x.n_chunks) ? masks[c] : 0ull;
-    const uint32_t pc = (uint32_t)__popcll(m);
-    // base = visible entities in the tiles before this one
-    uint32_t part = 0;
-    if (x.self_count) {  // 16 byte-counts per load; c0 is a multiple of 64
-        const uint4* __restrict__ c16 = reinterpret_cast<const uint4*>(x.viscnt + (uint64_t)f * x.cnt_stride);
-        for (uint32_t i = tid; i < c0 / 16; i += YH_BLOCK) {
-            const uint4 v = c16[i];
-            part = __builtin_amdgcn_udot4(v.x, 0x01010101u, part, false);
-            part = __builtin_amdgcn_udot4(v.y, 0x01010101u, part, false);
-            part = __builtin_amdgcn_udot4(v.z, 0x01010101u, part, false);
-            part = __builtin_amdgcn_udot4(v.w, 0x01010101u, part, false);
-        }
-    } else {
-        const uint32_t* __restrict__ cnt = x.tilecnt + (uint64_t)f * x.n_tiles;
-        for (uint32_t i = tid; i < t; i += YH_BLOCK) part += cnt[i];
-    }
-    const uint32_t base = block_sum_256(part, s_red);
-    // exclusive scan of the 256 popcounts
-    uint32_t inc = pc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_up(inc, o);
-        if ((int)lane >= o) inc += v;
-    }
-    if (lane == 63) s_red[wv] = inc;
-    s_mask[tid] = m;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (uint32_t w = 0; w < wv; ++w) wbase += s_red[w];
-    s_off[tid] = wbase + inc - pc;
-    const uint32_t own = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    __syncthreads();
-    if (tid == 0) {
-        if (t == 0) x.bcount_next[f] = 0;
-        if (t + 1 == x.n_tiles) {  // totals of this frustum, to the device (all-gather) and straight to the host
-            x.counts[f] = base + own;
-            x.host_counts[f] = base + own;
-            x.host_counts[YH_K_MAX_FRUSTA + f] = x.bcount_cur[f];
-        }
-    }
-    if (own == 0) return;
-    uint32_t* __restrict__ out = x.draw[f];
-    const uint32_t n_words = min(x.words, x.n_chunks - c0);
-#pragma unroll 8
-    for (uint32_t k = wv; k < n_words; k += 4) {
-        const uint64_t mk = s_mask[k];  // wave-uniform
-        if (mk) {
-            const uint64_t pos = (uint64_t)base + s_off[k] + lane_rank(mk);
-            if (((mk >> lane) & 1ull) && pos < x.draw_cap) out[pos] = ((c0 + k) << 6) + lane + x.id_base;
-        }
-    }
-}
+__global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) { expand_tile(x, blockIdx.x, blockIdx.y); }
 
 // The same sweep when changes are tracked (yh_scene_track_changes): one wave per 64-entity chunk first publishes
 // the ballot of "LocalTransform.dirty or WorldTransform.dirty" — every row this frame recomputed or found edited —

@@ -27,6 +27,7 @@ static_assert(YH_MAX_FRUSTA == YH_K_MAX_FRUSTA, "header / kernel frustum limits 
 struct yh_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    std::vector<struct yh_scene*> scenes;  // live scenes of this context (yh_wait flushes their deferred expansions)
     hipStream_t stream_c = nullptr;  // collectives of the no-host-sync gather (created by yh_comm_init)
     hipDeviceProp_t prop{};
     std::string err;
@@ -67,7 +68,14 @@ struct yh_scene {
     uint32_t n_chunks = 0, n_tiles = 0, tile_words = 64;
     uint32_t* h_counts = nullptr;     // host-mapped: written by k_expand ([f] totals, [8+f] boundary counts)
     uint32_t* h_counts_dev = nullptr; // device address of h_counts
-    uint32_t bparity = 0;             // which of the two boundary-counter sets this frame uses
+    uint32_t bset = 0;                // which of the three boundary-counter sets this frame uses
+    uint8_t* viscnt_alt = nullptr;    // byte counts of the other sets of visibility words: [YH_MASK_SETS-1][n_frusta][cnt_stride]
+    // Deferred expansion (TRS scenes of at most YH_SELF_COUNT_TILES tiles, YH_FRAME_ASYNC frames): the frame's
+    // k_expand is not launched; the first launch of the next frame carries it (k_frame_*_x), or the next
+    // synchronising / list-reading call launches it on its own.
+    bool exp_pending = false;
+    ExpandArgs pend;
+    uint32_t pend_frusta = 0;
     // change tracking (Mat4 scenes, yh_scene_track_changes): mask of rows a frame touched -> ascending slot list
     bool track = false;
     uint32_t* chg = nullptr;          // device: 32 count words | tile counts | mask words (one allocation)
@@ -139,6 +147,8 @@ struct yh_scene {
     bool mask_busy[YH_MASK_SETS] = {};  // ev_mask[p] must have passed before a frame writes word set p again
     bool gathered_async = false;  // h_all_counts holds running totals to be turned into counts after a sync
 };
+
+static int flush_expand(yh_scene* s);
 
 static thread_local std::string g_err;
 
@@ -244,6 +254,9 @@ extern "C" int yh_device_info_get(yh_ctx* ctx, yh_device_info* out) {
 
 extern "C" int yh_wait(yh_ctx* ctx) {
     if (!ctx) return fail(nullptr, YH_ERR_BAD_ARG, "yh_wait: ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (yh_scene* s : ctx->scenes)
+        if (int rc = flush_expand(s)) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->stream_c) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
     return YH_OK;
@@ -254,6 +267,8 @@ extern "C" void* yh_stream(yh_ctx* ctx) { return ctx ? (void*)ctx->stream : null
 // ------------------------------------------------------------------------------------------------ scene
 static void scene_free(yh_scene* s) {
     if (!s) return;
+    auto& live = s->ctx->scenes;
+    live.erase(std::remove(live.begin(), live.end(), s), live.end());
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->ctx->stream_c) (void)hipStreamSynchronize(s->ctx->stream_c);
@@ -277,7 +292,7 @@ static void scene_free(yh_scene* s) {
     if (s->ev_frame) (void)hipEventDestroy(s->ev_frame);
     for (hipEvent_t e : s->ev_mask)
         if (e) (void)hipEventDestroy(e);
-    for (void* p : {(void*)s->d_peer, (void*)s->gmask, (void*)s->send_pad, (void*)s->gtile, (void*)s->mask_alt})
+    for (void* p : {(void*)s->d_peer, (void*)s->gmask, (void*)s->send_pad, (void*)s->gtile, (void*)s->mask_alt, (void*)s->viscnt_alt})
         if (p) (void)hipFree(p);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -346,6 +361,13 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
         // byte popcounts of the words, rows of cnt_stride bytes read 16 at a time: 16-byte aligned start
         s->viscnt = (uint8_t*)(((uintptr_t)(s->vismask + F_alloc * s->n_chunks) + 15) & ~(uintptr_t)15);
     }
+    if (d->n_frusta) {  // the other set(s) of visibility words and of their byte counts (frames alternate)
+        const uint64_t wb = (uint64_t)(YH_MASK_SETS - 1) * F_alloc * s->n_chunks * 8, cb = (uint64_t)(YH_MASK_SETS - 1) * F_alloc * s->cnt_stride;
+        alloc((void**)&s->mask_alt, wb);
+        alloc((void**)&s->viscnt_alt, cb);
+        if (e == hipSuccess) e = hipMemsetAsync(s->mask_alt, 0, wb, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(s->viscnt_alt, 0, cb, ctx->stream);
+    }
     if (e == hipSuccess) e = hipHostMalloc((void**)&s->h_counts, 2 * YH_MAX_FRUSTA * 4, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&s->h_counts_dev, s->h_counts, 0);
     if (e == hipSuccess) e = hipEventCreate(&s->ev0);
@@ -373,6 +395,7 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
         scene_free(s);
         return code;
     }
+    ctx->scenes.push_back(s);
     *out = s;
     return YH_OK;
 }
@@ -385,7 +408,18 @@ static int check_range(yh_scene* s, const char* who, uint64_t first, uint64_t co
     return YH_OK;
 }
 
+// Launches the expansion a YH_FRAME_ASYNC frame left for the next frame's first launch to carry (stream order keeps
+// it behind that frame's kernels).  Called by everything that reads lists or totals, or synchronises.
+static int flush_expand(yh_scene* s) {
+    if (!s->exp_pending) return YH_OK;
+    s->exp_pending = false;
+    hipLaunchKernelGGL(k_expand, dim3(s->pend.n_tiles, s->pend_frusta), dim3(YH_BLOCK), 0, s->ctx->stream, s->pend);
+    HIP_TRY(s->ctx, hipGetLastError());
+    return YH_OK;
+}
+
 static int sync_scene(yh_scene* s) {
+    if (int rc = flush_expand(s)) return rc;
     HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
     if (s->ctx->stream_c) HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream_c));
     s->frame_pending = false;
@@ -864,6 +898,17 @@ static void launch_chain(int G, bool has_base, dim3 grid, hipStream_t st, Launch
     else launch_chain_g<BOUNDS, false>(G, grid, st, ev, a);
 }
 
+// First launch of a frame carrying the previous frame's expansion (levels from 0: no stored base parent).
+template <int BOUNDS>
+static void launch_first_x(int G, dim3 grid, hipStream_t st, LaunchEvents ev, const FrameArgs& a, const ExpandArgs& x) {
+    if (G <= 1) YH_LAUNCH((k_frame_trs_x<BOUNDS>), grid, st, ev, a, x);
+    else if (G <= 2) YH_LAUNCH((k_frame_chain_x<2, BOUNDS>), grid, st, ev, a, x);
+    else if (G <= 3) YH_LAUNCH((k_frame_chain_x<3, BOUNDS>), grid, st, ev, a, x);
+    else if (G <= 4) YH_LAUNCH((k_frame_chain_x<4, BOUNDS>), grid, st, ev, a, x);
+    else if (G <= 6) YH_LAUNCH((k_frame_chain_x<6, BOUNDS>), grid, st, ev, a, x);
+    else YH_LAUNCH((k_frame_chain_x<8, BOUNDS>), grid, st, ev, a, x);
+}
+
 template <int BOUNDS, bool HAS_BASE>
 static void launch_chain_mat4_g(int G, dim3 grid, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
     if (G <= 2) hipLaunchKernelGGL((k_chain_mat4<2, BOUNDS, HAS_BASE>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
@@ -921,9 +966,10 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     a.world = s->world;
     a.ldirty = s->ldirty;
     a.wdirty = s->wdirty;
-    a.bcount = s->counts + YH_MAX_FRUSTA * (1 + s->bparity);
+    a.bcount = s->counts + YH_MAX_FRUSTA * (1 + s->bset);
     // visibility words: two sets once the no-sync gather is in use (the collective stream still sends the last frame's)
     uint64_t* words = s->vismask;
+    uint8_t* byte_counts = s->viscnt;
     if (cull && s->mask_alt) {
         const uint32_t p = s->mparity;
         if (p % YH_MASK_HALF == 0) {  // about to rewrite sets p .. p+HALF-1: the latest gather that sent one of them
@@ -935,10 +981,13 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
                 }
             if (latest >= 0) HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_mask[latest], 0));
         }
-        if (p) words = s->mask_alt + (uint64_t)(p - 1) * s->desc.n_frusta * s->n_chunks;
+        if (p) {
+            words = s->mask_alt + (uint64_t)(p - 1) * s->desc.n_frusta * s->n_chunks;
+            byte_counts = s->viscnt_alt + (uint64_t)(p - 1) * s->desc.n_frusta * s->cnt_stride;
+        }
     }
     a.vismask = words;
-    a.viscnt = s->viscnt;
+    a.viscnt = byte_counts;
     a.cnt_stride = s->cnt_stride;
     a.n_chunks = s->n_chunks;
     a.n_frusta = cull ? n_frusta : 0;
@@ -988,6 +1037,8 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     };
 
     if (s->desc.local_kind == YH_LOCAL_TRS) {
+        if (s->exp_pending && (s->groups.empty() || s->groups[0].lo != 0 || s->level_offsets[s->groups[0].hi + 1] == s->level_offsets[0]))
+            if (int rc = flush_expand(s)) return rc;
         for (uint32_t gi = 0; gi < s->groups.size(); ++gi) {
             const LevelGroup g = s->groups[gi];
             a.begin = s->level_offsets[g.lo];
@@ -995,7 +1046,19 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
             if (a.end == a.begin) continue;
             const bool has_base = g.lo > 0;
             const LaunchEvents ev = time_launch(gi);
-            if (g.hi > g.lo) {
+            if (s->exp_pending && !has_base) {  // this launch carries the previous frame's expansion
+                ExpandArgs xf = s->pend;
+                xf.fuse_blocks = xf.n_tiles * s->pend_frusta;
+                s->exp_pending = false;
+                for (uint32_t j = 0; j < YH_MAX_GROUP; ++j)
+                    a.lvl_begin[j] = (g.lo + 1 + j <= g.hi) ? s->level_offsets[g.lo + 1 + j] : 0xFFFFFFFFu;
+                dim3 grid = grid_for(a);
+                grid.x += xf.fuse_blocks;
+                const int G = (int)(g.hi - g.lo + 1);
+                if (bounds == 0) launch_first_x<0>(G, grid, st, ev, a, xf);
+                else if (bounds == 1) launch_first_x<1>(G, grid, st, ev, a, xf);
+                else launch_first_x<2>(G, grid, st, ev, a, xf);
+            } else if (g.hi > g.lo) {
                 for (uint32_t j = 0; j < YH_MAX_GROUP; ++j)
                     a.lvl_begin[j] = (g.lo + 1 + j <= g.hi) ? s->level_offsets[g.lo + 1 + j] : 0xFFFFFFFFu;
                 const dim3 grid = grid_for(a);
@@ -1080,14 +1143,16 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         s->last_mask = words;
         s->last_mparity = s->mparity;
         if (s->mask_alt) s->mparity = (s->mparity + 1u) % YH_MASK_SETS;
-        x.viscnt = s->viscnt;
+        x.viscnt = byte_counts;
         x.cnt_stride = s->cnt_stride;
         x.tilecnt = s->tilecnt;
         x.counts = s->counts;
-        x.bcount_cur = s->counts + YH_MAX_FRUSTA * (1 + s->bparity);
-        x.bcount_next = s->counts + YH_MAX_FRUSTA * (2 - s->bparity);
+        // three sets of boundary counters: this frame's, the next frame's (its launches may already be adding to it
+        // when a deferred expansion runs) and the one after, which this expansion zeroes
+        x.bcount_cur = s->counts + YH_MAX_FRUSTA * (1 + s->bset);
+        x.bcount_next = s->counts + YH_MAX_FRUSTA * (1 + (s->bset + 2u) % 3u);
         x.host_counts = s->h_counts_dev;
-        s->bparity ^= 1u;
+        s->bset = (s->bset + 1u) % 3u;
         for (uint32_t f = 0; f < YH_MAX_FRUSTA; ++f) x.draw[f] = s->draw[f];
         x.draw_cap = s->draw_cap;
         x.n_chunks = s->n_chunks;
@@ -1101,10 +1166,20 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
             HIP_TRY(ctx, hipGetLastError());
             ++launches;
         }
-        hipLaunchKernelGGL(k_expand, dim3(s->n_tiles, n_frusta), dim3(YH_BLOCK), 0, st, x);
-        HIP_TRY(ctx, hipGetLastError());
+        // Small TRS scenes, frames enqueued without a host sync: leave the expansion to the next frame's first launch
+        // (or to whatever reads the lists first) — its own dependent launch is a tenth of such a frame.
+        const bool defer = (flags & YH_FRAME_ASYNC) && s->desc.local_kind == YH_LOCAL_TRS && x.self_count &&
+                           !(s->kernel_timing && s->timing_only == -1);
+        if (defer) {
+            s->pend = x;
+            s->pend_frusta = n_frusta;
+            s->exp_pending = true;
+        } else {
+            hipLaunchKernelGGL(k_expand, dim3(s->n_tiles, n_frusta), dim3(YH_BLOCK), 0, st, x);
+            HIP_TRY(ctx, hipGetLastError());
+            ++launches;
+        }
         if (int rc = time_end()) return rc;
-        ++launches;
     }
     if (frame_events) HIP_TRY(ctx, hipEventRecord(s->ev1, st));
     s->frame_timed = frame_events;
@@ -1169,6 +1244,7 @@ extern "C" int yh_build_object_data(yh_scene* s, uint32_t frustum, uint32_t batc
     yh_ctx* ctx = s->ctx;
     if (frustum >= s->last_n_frusta) return fail(ctx, YH_ERR_STATE, "yh_build_object_data: frustum %u was not culled by the last frame", frustum);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = flush_expand(s)) return rc;
     if (!s->obj[frustum]) {
         HIP_TRY(ctx, hipMalloc((void**)&s->obj[frustum], s->draw_cap * 64));
         HIP_TRY(ctx, hipMalloc((void**)&s->cmd[frustum], s->draw_cap * 16));
@@ -1193,6 +1269,7 @@ extern "C" int yh_build_mesh_buckets(yh_scene* s, uint32_t frustum, uint32_t bat
     if (s->n_meshes < 1 || s->n_meshes > YH_BUCKET_MAX_MESHES)
         return fail(ctx, YH_ERR_UNSUPPORTED, "yh_build_mesh_buckets: %u meshes, 1..%u supported", s->n_meshes, YH_BUCKET_MAX_MESHES);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = flush_expand(s)) return rc;
     if (!s->obj[frustum]) {
         HIP_TRY(ctx, hipMalloc((void**)&s->obj[frustum], s->draw_cap * 64));
         HIP_TRY(ctx, hipMalloc((void**)&s->cmd[frustum], s->draw_cap * 16));
@@ -1770,9 +1847,7 @@ static int gather_setup(yh_scene* s) {
         HIP_TRY(ctx, hipMalloc((void**)&s->send_pad, (uint64_t)F * words * 8));
         HIP_TRY(ctx, hipMemsetAsync(s->send_pad, 0, (uint64_t)F * words * 8, ctx->stream));
     }
-    HIP_TRY(ctx, hipMalloc((void**)&s->mask_alt, (uint64_t)(YH_MASK_SETS - 1) * F * s->n_chunks * 8));
-    // (on the context's stream and waited for: the null stream's fills are not ordered with our non-blocking streams)
-    HIP_TRY(ctx, hipMemsetAsync(s->mask_alt, 0, (uint64_t)(YH_MASK_SETS - 1) * F * s->n_chunks * 8, ctx->stream));
+    // (fills go on the context's stream and are waited for: the null stream is not ordered with our non-blocking streams)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (uint32_t f = 0; f < F; ++f) {
         const uint64_t cap = (uint64_t)R * words * 64;
