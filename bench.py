@@ -43,7 +43,7 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--entities", type=int, default=0, help="override entities per GPU")
@@ -321,11 +321,11 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # timed region: K frames; on every 8th / 4th frame (at least 25 samples) the transform launches carry a pair of
-    # HIP events each (hipExtLaunchKernelGGL on the library's stream: the dispatch's own start/end timestamps, the
+    # timed region: K frames; on every (K / 25)-th frame, at most every 16th (25 samples at the default K = 400), the
+    # transform launches carry a pair of HIP events each (hipExtLaunchKernelGGL on the library's stream: the dispatch's own start/end timestamps, the
     # ones rocprofv3's kernel trace reports; nothing is added to the stream).  All transform launches of a sampled
     # frame, not just the dominant one: a launch whose predecessor is not instrumented reads ~3 us long.
-    period = 8 if args.steps >= 200 else 4 if args.steps >= 100 else 1
+    period = max(1, min(16, args.steps // 25))
     if not args.no_kernel_events:
         scene.set_kernel_timing(-1, period)
     t0 = time.perf_counter()

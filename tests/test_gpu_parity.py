@@ -201,6 +201,12 @@ def test_planner_groups_small_levels_and_triples_large_ones(ctx, oracle):
         with Scene(ctx, n, n_levels=8, n_frusta=0, bounds_kind=0) as s:
             s.upload_hierarchy(oracle.synth_parents(lo), lo)
             assert [int(q[1]) for q in s.groups()] == expect
+    # culling scenes small enough for the expansion to ride on the next frame's first launch: a lighter first launch
+    for n, expect in ((1_000_000, [4, 7]), (500_000, [5, 7]), (250_000, [7]), (12_500_000, [1, 4, 7])):
+        lo = oracle.synth_level_offsets(n, 8)
+        with Scene(ctx, n, n_levels=8, n_frusta=1) as s:
+            s.upload_hierarchy(oracle.synth_parents(lo), lo)
+            assert [int(q[1]) for q in s.groups()] == expect
 
 
 def test_deep_and_uneven_hierarchy(ctx, oracle):

@@ -430,7 +430,8 @@ static int sync_scene(yh_scene* s) {
 // parent's flag of this frame).  Measured on MI355X with tools/plan_sweep.py over all 128 cuts of the 8-level
 // 2^k trees of 1M and 12.5M entities (profiles/r01/plan_sweep_*.txt): every dependent launch costs 2-6 us, a chain
 // group costs its deepest entity's dependent walk, so
-//   - levels whose sum fits one residency of the chip (~320k lanes) share one launch, up to 8 levels;
+//   - levels whose sum fits one residency of the chip (~320k lanes) share one launch, up to 8 levels (the first
+//     launch of a small scene that needs a second one: ~128k, see below);
 //   - larger levels go three to a launch (one or two ancestors re-derived per entity beats a launch boundary
 //     and the 64-byte parent gather even at 6M entities per level), the short group first.
 // An explicit plan or grouping (yh_scene_set_plan / yh_scene_set_grouping) replaces this.
@@ -442,9 +443,14 @@ static int plan_groups(yh_scene* s) {
         return YH_OK;
     }
     auto span = [&](uint32_t lo, uint32_t hi) -> uint64_t { return (uint64_t)s->level_offsets[hi + 1] - s->level_offsets[lo]; };
-    const uint64_t resident = 320 * 1024;
+    // Scenes whose expansion rides on the next frame's first launch (small TRS scenes, see yh_frame) do better with a
+    // lighter first launch once they need a second one anyway: 1M entities 34.5 us for 0..4 | 5..7 against 35.1 for
+    // 0..5 | 6..7, 500k 22.2 us for 0..5 | 6..7 against 23.4 for 0..6 | 7; a 250k scene stays one launch (13.9 us).
+    const bool rides = s->desc.local_kind == YH_LOCAL_TRS && s->desc.bounds_kind != YH_BOUNDS_NONE &&
+                       s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES && s->n > 320 * 1024;
     uint32_t lo = 0;
     while (lo < L) {
+        const uint64_t resident = (lo == 0 && rides) ? 128 * 1024 : 320 * 1024;
         uint32_t hi = lo;
         if (s->max_group_levels == 1) {
             // one level per launch
