@@ -41,6 +41,7 @@ struct FrameArgs {
     uint32_t cnt_stride; // n_chunks rounded up to 16 (rows are read as uint4)
     uint32_t n_chunks;
     uint32_t begin, end;               // entity range of this launch (levels lo..hi)
+    uint32_t n_tiles, xcd_per;         // 256-entity tiles of the launch; tiles per XCD (0: tile = workgroup index)
     uint32_t lvl_begin[YH_MAX_GROUP];  // chain kernel: first slot of levels lo+1, lo+2, ... (0xFFFFFFFF when absent)
     uint32_t n_frusta;
     uint32_t id_base;
@@ -253,6 +254,13 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t 
 // register double buffer of the next slice's inputs were measured and dropped: DESIGN.md §4).  BOUNDS: 0 none,
 // 1 per-entity planes, 2 mesh table.  HAS_BASE: the level is > 0 (its entities have stored parents), else the
 // parent is the scene root.
+// Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, each XCD has its own L2).  Mapping
+// workgroup b to tile (b % 8) * per + b / 8 gives every XCD one contiguous run of tiles, so the parent rows that
+// neighbouring tiles of sorted siblings share are fetched into ONE L2 instead of up to eight.
+__device__ __forceinline__ uint32_t xcd_tile(const FrameArgs& a, const uint32_t b) {
+    return a.xcd_per ? (b & 7u) * a.xcd_per + (b >> 3) : b;
+}
+
 template <int BOUNDS, bool HAS_BASE>
 __device__ __forceinline__ void frame_trs_tile(const FrameArgs& a, const uint32_t tile) {
     const uint32_t tid = threadIdx.x;
@@ -340,11 +348,13 @@ __device__ __forceinline__ void frame_chain_tile(const FrameArgs& a, const uint3
 
 template <int BOUNDS, bool HAS_BASE>
 __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs(const FrameArgs a) {
-    frame_trs_tile<BOUNDS, HAS_BASE>(a, blockIdx.x);
+    const uint32_t tile = xcd_tile(a, blockIdx.x);
+    if (tile < a.n_tiles) frame_trs_tile<BOUNDS, HAS_BASE>(a, tile);
 }
 template <int G, int BOUNDS, bool HAS_BASE>
 __global__ __launch_bounds__(YH_BLOCK) void k_frame_chain(const FrameArgs a) {
-    frame_chain_tile<G, BOUNDS, HAS_BASE>(a, blockIdx.x);
+    const uint32_t tile = xcd_tile(a, blockIdx.x);
+    if (tile < a.n_tiles) frame_chain_tile<G, BOUNDS, HAS_BASE>(a, tile);
 }
 // The first launch of a frame (levels from 0: no stored base parent) with the PREVIOUS frame's expansion on board: the
 // launch's first x.fuse_blocks workgroups run expand_tile on the previous frame's words, the others are the frame's
@@ -358,7 +368,8 @@ __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs_x(const FrameArgs a, con
         expand_tile(x, blockIdx.x % x.n_tiles, blockIdx.x / x.n_tiles);
         return;
     }
-    frame_trs_tile<BOUNDS, false>(a, blockIdx.x - x.fuse_blocks);
+    const uint32_t tile = xcd_tile(a, blockIdx.x - x.fuse_blocks);
+    if (tile < a.n_tiles) frame_trs_tile<BOUNDS, false>(a, tile);
 }
 template <int G, int BOUNDS>
 __global__ __launch_bounds__(YH_BLOCK) void k_frame_chain_x(const FrameArgs a, const ExpandArgs x) {
@@ -366,7 +377,8 @@ __global__ __launch_bounds__(YH_BLOCK) void k_frame_chain_x(const FrameArgs a, c
         expand_tile(x, blockIdx.x % x.n_tiles, blockIdx.x / x.n_tiles);
         return;
     }
-    frame_chain_tile<G, BOUNDS, false>(a, blockIdx.x - x.fuse_blocks);
+    const uint32_t tile = xcd_tile(a, blockIdx.x - x.fuse_blocks);
+    if (tile < a.n_tiles) frame_chain_tile<G, BOUNDS, false>(a, tile);
 }
 
 // ---------------------------------------------------------------------------------------------------

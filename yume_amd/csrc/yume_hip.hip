@@ -1002,8 +1002,13 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     memcpy(a.root, s->root, sizeof a.root);
     if (cull) memcpy(a.planes, planes, (size_t)n_frusta * 24 * sizeof(float));
     const int bounds = cull ? (int)s->desc.bounds_kind : 0;
-    auto grid_for = [&](const FrameArgs& fa) -> dim3 {
-        return dim3(cdiv((uint64_t)fa.end - (fa.begin & ~63u), YH_BLOCK));  // chunk-aligned 256-entity tiles
+    // XCD-contiguous tile order (xcd_tile) only for the launch of a flat TRS scene: measured +4 % at 256M instances
+    // (4.98 -> 4.78 ms), nothing at 16M x 5 frusta, but -2 % / -4.5 % on the tree launches of cfg2 / cfg4 (eight
+    // distant regions of parents in flight at once), which therefore keep workgroup order.
+    auto grid_for = [&](FrameArgs& fa, bool flat_scene = false) -> dim3 {
+        fa.n_tiles = (uint32_t)cdiv((uint64_t)fa.end - (fa.begin & ~63u), YH_BLOCK);  // chunk-aligned 256-entity tiles
+        fa.xcd_per = (flat_scene && fa.n_tiles >= 64) ? (fa.n_tiles + 7u) / 8u : 0u;
+        return dim3(fa.xcd_per ? fa.xcd_per * 8u : fa.n_tiles);
     };
 
     const bool frame_events = s->kernel_timing && s->timing_only == -1 && (s->frames % s->timing_period == 0);
@@ -1058,7 +1063,7 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
                 s->exp_pending = false;
                 for (uint32_t j = 0; j < YH_MAX_GROUP; ++j)
                     a.lvl_begin[j] = (g.lo + 1 + j <= g.hi) ? s->level_offsets[g.lo + 1 + j] : 0xFFFFFFFFu;
-                dim3 grid = grid_for(a);
+                dim3 grid = grid_for(a, s->desc.n_levels == 1);
                 grid.x += xf.fuse_blocks;
                 const int G = (int)(g.hi - g.lo + 1);
                 if (bounds == 0) launch_first_x<0>(G, grid, st, ev, a, xf);
@@ -1073,7 +1078,7 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
                 else if (bounds == 1) launch_chain<1>(G, has_base, grid, st, ev, a);
                 else launch_chain<2>(G, has_base, grid, st, ev, a);
             } else {
-                const dim3 grid = grid_for(a);
+                const dim3 grid = grid_for(a, s->desc.n_levels == 1);
                 if (bounds == 0) launch_trs<0>(has_base, grid, st, ev, a);
                 else if (bounds == 1) launch_trs<1>(has_base, grid, st, ev, a);
                 else launch_trs<2>(has_base, grid, st, ev, a);
