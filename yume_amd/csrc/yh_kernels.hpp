@@ -41,7 +41,7 @@ struct FrameArgs {
     uint32_t cnt_stride; // n_chunks rounded up to 16 (rows are read as uint4)
     uint32_t n_chunks;
     uint32_t begin, end;               // entity range of this launch (levels lo..hi)
-    uint32_t n_tiles, xcd_per;         // 256-entity tiles of the launch; tiles per XCD (0: tile = workgroup index)
+    uint32_t n_tiles, xcd_per, xcd_k;  // 256-entity tiles of the launch; XCD-aware order (both 0: tile = workgroup index)
     uint32_t lvl_begin[YH_MAX_GROUP];  // chain kernel: first slot of levels lo+1, lo+2, ... (0xFFFFFFFF when absent)
     uint32_t n_frusta;
     uint32_t id_base;
@@ -254,10 +254,15 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t 
 // register double buffer of the next slice's inputs were measured and dropped: DESIGN.md §4).  BOUNDS: 0 none,
 // 1 per-entity planes, 2 mesh table.  HAS_BASE: the level is > 0 (its entities have stored parents), else the
 // parent is the scene root.
-// Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, each XCD has its own L2).  Mapping
-// workgroup b to tile (b % 8) * per + b / 8 gives every XCD one contiguous run of tiles, so the parent rows that
-// neighbouring tiles of sorted siblings share are fetched into ONE L2 instead of up to eight.
+// Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, each XCD has its own L2).  xcd_k: every
+// XCD takes runs of xcd_k consecutive tiles, so the parent rows that neighbouring tiles of sorted siblings share are
+// fetched into ONE L2 instead of up to eight, while all XCDs keep working in the same region of the arrays (tree
+// launches).  xcd_per: one contiguous run of tiles per XCD (flat scenes).  The host picks what was measured faster.
 __device__ __forceinline__ uint32_t xcd_tile(const FrameArgs& a, const uint32_t b) {
+    if (a.xcd_k) {
+        const uint32_t grp = b >> 3, x = b & 7u;
+        return ((grp / a.xcd_k) * 8u + x) * a.xcd_k + grp % a.xcd_k;
+    }
     return a.xcd_per ? (b & 7u) * a.xcd_per + (b >> 3) : b;
 }
 

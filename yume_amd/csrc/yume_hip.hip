@@ -42,6 +42,7 @@ struct LevelGroup {
 };
 
 #define YH_TIMING_RING 2048
+#define YH_XCD_RUN 8u /* consecutive tiles one XCD takes in a tree launch */
 #define YH_MASK_SETS 2u /* sets of visibility words frames rotate through while a gather is in flight */
 #define YH_MASK_HALF 1u /* the frames' stream checks on the gather every YH_MASK_HALF-th frame (8 / 4 measured the same) */
 
@@ -1002,13 +1003,21 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     memcpy(a.root, s->root, sizeof a.root);
     if (cull) memcpy(a.planes, planes, (size_t)n_frusta * 24 * sizeof(float));
     const int bounds = cull ? (int)s->desc.bounds_kind : 0;
-    // XCD-contiguous tile order (xcd_tile) only for the launch of a flat TRS scene: measured +4 % at 256M instances
-    // (4.98 -> 4.78 ms), nothing at 16M x 5 frusta, but -2 % / -4.5 % on the tree launches of cfg2 / cfg4 (eight
-    // distant regions of parents in flight at once), which therefore keep workgroup order.
+    // XCD-aware tile order (xcd_tile), as measured: the launch of a flat scene gives every XCD one contiguous run of
+    // tiles (256M instances 4.98 -> 4.77 ms; runs of 64-512 tiles do the same, runs of 8 are slower than no mapping);
+    // tree launches give every XCD runs of 8 consecutive tiles (2048 sorted siblings share their parents' lines in
+    // one L2 while all XCDs still work in the same region: cfg2 36.0 -> 34.4 us, cfg4 0.372 -> 0.368 ms; runs of 2-4
+    // or 16-64 gain less, one contiguous run per XCD LOSES 2-4.5 %).
     auto grid_for = [&](FrameArgs& fa, bool flat_scene = false) -> dim3 {
         fa.n_tiles = (uint32_t)cdiv((uint64_t)fa.end - (fa.begin & ~63u), YH_BLOCK);  // chunk-aligned 256-entity tiles
-        fa.xcd_per = (flat_scene && fa.n_tiles >= 64) ? (fa.n_tiles + 7u) / 8u : 0u;
-        return dim3(fa.xcd_per ? fa.xcd_per * 8u : fa.n_tiles);
+        fa.xcd_per = fa.xcd_k = 0;
+        if (s->desc.local_kind != YH_LOCAL_TRS || fa.n_tiles < 64) return dim3(fa.n_tiles);
+        if (flat_scene) {
+            fa.xcd_per = (fa.n_tiles + 7u) / 8u;
+            return dim3(fa.xcd_per * 8u);
+        }
+        fa.xcd_k = YH_XCD_RUN;
+        return dim3((fa.n_tiles + 8u * YH_XCD_RUN - 1u) / (8u * YH_XCD_RUN) * (8u * YH_XCD_RUN));
     };
 
     const bool frame_events = s->kernel_timing && s->timing_only == -1 && (s->frames % s->timing_period == 0);
