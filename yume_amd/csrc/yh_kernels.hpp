@@ -394,7 +394,9 @@ __global__ __launch_bounds__(YH_BLOCK) void k_frame_chain_x(const FrameArgs a, c
 template <int BOUNDS, bool HAS_BASE>
 __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, const uint32_t root_dirty) {
     const uint32_t tid = threadIdx.x;
-    const uint64_t e64 = (uint64_t)(a.begin & ~63u) + (uint64_t)blockIdx.x * YH_BLOCK + tid;
+    const uint32_t tile = xcd_tile(a, blockIdx.x);
+    if (tile >= a.n_tiles) return;
+    const uint64_t e64 = (uint64_t)(a.begin & ~63u) + (uint64_t)tile * YH_BLOCK + tid;
     if (e64 - (tid & 63u) >= a.end) return;  // this wave's chunk starts past the end (wave-uniform)
     const bool valid = e64 >= a.begin && e64 < a.end;
     const uint32_t e = (uint32_t)e64;
@@ -459,7 +461,9 @@ __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, cons
 template <int G, int BOUNDS, bool HAS_BASE>
 __global__ __launch_bounds__(YH_BLOCK) void k_chain_mat4(const FrameArgs a, const uint32_t root_dirty) {
     const uint32_t tid = threadIdx.x;
-    const uint64_t e64 = (uint64_t)(a.begin & ~63u) + (uint64_t)blockIdx.x * YH_BLOCK + tid;
+    const uint32_t tile = xcd_tile(a, blockIdx.x);
+    if (tile >= a.n_tiles) return;
+    const uint64_t e64 = (uint64_t)(a.begin & ~63u) + (uint64_t)tile * YH_BLOCK + tid;
     if (e64 - (tid & 63u) >= a.end) return;  // wave-uniform
     const bool valid = e64 >= a.begin && e64 < a.end;
     const uint32_t e = (uint32_t)e64;

@@ -1007,11 +1007,11 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     // tiles (256M instances 4.98 -> 4.77 ms; runs of 64-512 tiles do the same, runs of 8 are slower than no mapping);
     // tree launches give every XCD runs of 8 consecutive tiles (2048 sorted siblings share their parents' lines in
     // one L2 while all XCDs still work in the same region: cfg2 36.0 -> 34.4 us, cfg4 0.372 -> 0.368 ms; runs of 2-4
-    // or 16-64 gain less, one contiguous run per XCD LOSES 2-4.5 %).
+    // or 16-64 gain less, one contiguous run per XCD LOSES 2-4.5 %; the Mat4 level kernels gain 1.5-2.5 % on trees).
     auto grid_for = [&](FrameArgs& fa, bool flat_scene = false) -> dim3 {
         fa.n_tiles = (uint32_t)cdiv((uint64_t)fa.end - (fa.begin & ~63u), YH_BLOCK);  // chunk-aligned 256-entity tiles
         fa.xcd_per = fa.xcd_k = 0;
-        if (s->desc.local_kind != YH_LOCAL_TRS || fa.n_tiles < 64) return dim3(fa.n_tiles);
+        if (fa.n_tiles < 64 || (s->desc.local_kind != YH_LOCAL_TRS && s->desc.n_levels == 1)) return dim3(fa.n_tiles);
         if (flat_scene) {
             fa.xcd_per = (fa.n_tiles + 7u) / 8u;
             return dim3(fa.xcd_per * 8u);
