@@ -5,6 +5,8 @@ Bar: world matrices equal as IEEE values element for element (zero tolerance; th
 of a zero, see yh_math.hpp m4_compose) — far inside north_star's 1e-5 relative; visible-index SETS exact;
 boundary counts exact.  NaN positions must coincide.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -229,6 +231,51 @@ def test_deep_and_uneven_hierarchy(ctx, oracle):
             s.frame(planes)
             assert_same_values(s.world_soa(), exp["m"].T, f"world g={group}")
             assert np.array_equal(s.draw_list(0), np.flatnonzero(vis[0]).astype(np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("YH_FUZZ_SEEDS", "12"))))  # more seeds: YH_FUZZ_SEEDS=300
+def test_random_scene_shapes_plans_and_frame_sequences(ctx, oracle, seed):
+    """Seeded random differential test: level counts 1..12, uneven level sizes from a few entities to ~200k (so that
+    launches below and above the XCD-ordering threshold, ragged tiles and chunk-straddling level boundaries all occur),
+    random launch plans, id offsets, 1..4 frusta, and a random mix of synchronous and YH_FRAME_ASYNC frames (deferred
+    expansion riding on the next frame).  World matrices, lists and boundary counts must equal the oracle's."""
+    from yume_amd import _lib
+
+    rng = np.random.default_rng(1000 + seed)
+    n_levels = int(rng.integers(1, 13))
+    sizes = [int(rng.choice([rng.integers(1, 70), rng.integers(70, 5000), rng.integers(5000, 200_000)], p=[0.2, 0.4, 0.4]))
+             for _ in range(n_levels)]
+    lo = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    n = int(lo[-1])
+    par = oracle.synth_parents(lo, seed=seed)
+    trs = oracle.synth_trs(n, int(lo[1]), seed=seed)
+    bounds = oracle.synth_aabb(n, seed=seed)
+    base = int(rng.integers(0, 1 << 20))
+    cams = np.concatenate([oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()[:3]])
+    exp_w = oracle.frame_trs(trs, par, lo, n_threads=8)
+    vis_all, bnd_all = oracle.cull(exp_w, bounds, cams, n_threads=8)
+    with gpu_scene(ctx, lo, par, trs, bounds, 4, id_base=base) as s:
+        for rnd in range(6):
+            if rng.random() < 0.5:  # a random plan: cut points between levels, at most 8 levels per group
+                cuts = sorted(set(rng.choice(n_levels, size=int(rng.integers(1, n_levels + 1)), replace=False).tolist()) | {n_levels - 1})
+                ok, prev = True, -1
+                for c in cuts:
+                    ok &= c - prev <= 8
+                    prev = c
+                s.set_plan(cuts if ok else [])
+            else:
+                s.set_plan([])
+            nf = int(rng.integers(1, 5))
+            for _ in range(int(rng.integers(0, 4))):  # frames that are overwritten before anyone looks
+                s.frame(cams[: int(rng.integers(1, 5))], _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC)
+            s.frame(cams[:nf], _lib.YH_FRAME_ALL_DIRTY | (_lib.YH_FRAME_ASYNC if rng.random() < 0.7 else 0))
+            counts, bcounts = s.counts()
+            for f in range(nf):
+                exp_set = np.flatnonzero(vis_all[f]).astype(np.uint32) + np.uint32(base)
+                assert counts[f] == exp_set.size and bcounts[f] == np.count_nonzero(bnd_all[f]), (seed, rnd, f, s.groups().tolist())
+                assert np.array_equal(s.draw_list(f), exp_set), (seed, rnd, f, s.groups().tolist())
+            if rnd % 3 == 0:
+                assert_same_values(s.world_soa(), exp_w["m"].T, f"world seed {seed} round {rnd}")
 
 
 def test_cfg3_five_frusta_1m(ctx, oracle):
