@@ -1,6 +1,8 @@
 """GPU parity of the drop-in column path: flecs 68-byte {Mat4, dirty} columns in, the literal three-branch
 rule of TransformSyncSystem.zig:60-73 + the PostTransform dirty reset on the device, columns out — checked
 frame after frame against the oracle's reference-faithful AoS system."""
+import os
+
 import numpy as np
 import pytest
 
@@ -114,6 +116,89 @@ def test_dirty_frames_match_reference_system(ctx, oracle):
         root["dirty"] = 1
         s.set_root(root["m"][0])
         step("frame 6 (root moved)")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("YH_FUZZ_SEEDS", "8"))))
+def test_random_edit_scripts_on_flecs_columns(ctx, oracle, seed):
+    """Seeded random differential test of the literal three-branch rule: random level shapes (1..10 uneven levels, so
+    single-level and chain launches, XCD-ordered and plain ones all occur), and per frame a random mix of local edits,
+    world-only edits (inverse branch), singular matrices and root moves, uploaded as sparse rows; change tracking on in
+    half the runs.  After every frame both device columns, dirty bytes, the draw list and (when tracked) the changed
+    rows must be what the oracle's CPU systems leave."""
+    from yume_amd import Scene, _lib
+
+    rng = np.random.default_rng(5000 + seed)
+    n_levels = int(rng.integers(1, 11))
+    sizes = [int(rng.choice([rng.integers(1, 70), rng.integers(70, 3000), rng.integers(3000, 60_000)], p=[0.2, 0.4, 0.4]))
+             for _ in range(n_levels)]
+    lo = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    n = int(lo[-1])
+    par = oracle.synth_parents(lo, seed=seed)
+    bounds = oracle.synth_aabb(n, seed=seed)
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo[1]), seed=seed))
+    world = np.zeros(n, oracle.T68)
+    world["m"][:, [0, 5, 10, 15]] = 1
+    world["dirty"] = 1
+    root = oracle.identity68()
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    track = bool(seed % 2)
+
+    def rnd_m(scale):
+        return oracle.compose(rng.uniform(-scale, scale, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+
+    with Scene(ctx, n, n_levels=n_levels, n_frusta=1, local_kind=_lib.YH_LOCAL_MAT4) as s:
+        s.upload_hierarchy(par, lo)
+        s.upload_aabb(np.ascontiguousarray(bounds[:, 0:3].T), np.ascontiguousarray(bounds[:, 3:6].T))
+        s.upload_local_aos68(local)
+        s.upload_world_aos68(world)
+        s.track_changes(track)
+        for frame in range(7):
+            if frame >= 1:
+                kind = rng.random()
+                if kind < 0.15:
+                    pass  # nothing moves
+                else:
+                    k = int(rng.integers(1, max(2, n // 20)))
+                    idx = np.unique(rng.integers(0, n, k)).astype(np.uint32)
+                    for e in idx:
+                        local["m"][e] = 0 if rng.random() < 0.02 else rnd_m(5)
+                    local["dirty"][idx] = 1
+                    s.upload_local_rows(idx, local[idx])
+                    if rng.random() < 0.6:  # world-only edits elsewhere (gizmo drags)
+                        widx = np.setdiff1d(np.unique(rng.integers(0, n, max(1, k // 3))).astype(np.uint32), idx)
+                        for e in widx:
+                            world["m"][e] = rnd_m(50)
+                        world["dirty"][widx] = 1
+                        if widx.size:
+                            s.upload_world_rows(widx, world[widx])
+                    if rng.random() < 0.2:
+                        root["m"][0] = rnd_m(3)
+                        root["dirty"] = 1
+                        s.set_root(root["m"][0])
+            before_dirty = (local["dirty"] | world["dirty"]).astype(bool)
+            w0 = world["m"].copy()
+            oracle.frame_aos68(world, local, par, lo, root)
+            s.frame(planes, flags=0)
+            gw, gl = s.world_aos68(), s.local_aos68()
+            with np.errstate(all="ignore"):
+                assert_same_values(gw["m"], world["m"], f"seed {seed} frame {frame}: world")
+                assert_same_values(gl["m"], local["m"], f"seed {seed} frame {frame}: local")
+            assert not gw["dirty"].any() and not gl["dirty"].any()
+            with np.errstate(all="ignore"):
+                vis, bnd = oracle.cull(world, bounds, planes)
+            assert np.array_equal(s.draw_list(0), np.flatnonzero(vis[0]).astype(np.uint32)), (seed, frame)
+            if track:
+                slots, wr, lr = s.changed()
+                assert np.all(np.diff(slots.astype(np.int64)) > 0)
+                touched = np.zeros(n, bool)
+                touched[slots] = True
+                # every row that was dirty before the sweep or whose world matrix changed must be reported
+                with np.errstate(all="ignore"):
+                    moved = ~np.all((w0 == world["m"]) | (np.isnan(w0) & np.isnan(world["m"])), axis=1)
+                assert np.all(touched[before_dirty]) and np.all(touched[moved]), (seed, frame)
+                with np.errstate(all="ignore"):
+                    assert_same_values(wr["m"], world["m"][slots], "changed world rows")
+                    assert_same_values(lr["m"], local["m"][slots], "changed local rows")
 
 
 def test_sparse_rows_and_change_tracking(ctx, oracle):
