@@ -365,8 +365,9 @@ __global__ __launch_bounds__(YH_BLOCK) void k_frame_chain(const FrameArgs a) {
 // launch's first x.fuse_blocks workgroups run expand_tile on the previous frame's words, the others are the frame's
 // own tiles.  For scenes of up to ~1M entities a frame is a handful of 5-20 us launches and the expansion's own
 // dependent launch is a tenth of it (cfg2: 41.1 -> 37.5 us per frame); the two halves touch different word sets,
-// count bytes and boundary counters (the host alternates them).  Larger scenes keep the separate k_expand launch
-// (measured: nothing to gain, and the extra LDS and arguments cost the big kernels 1-2 %).
+// count bytes and boundary counters (the host alternates them).  Larger trees whose first launch is a small one use
+// it too (1.5-2 %); flat large scenes keep the separate k_expand launch (the extra LDS and arguments cost their one
+// big kernel 1-2 %, more than the boundary).
 template <int BOUNDS>
 __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs_x(const FrameArgs a, const ExpandArgs x) {
     if (blockIdx.x < x.fuse_blocks) {
