@@ -1848,6 +1848,17 @@ static int gather_setup(yh_scene* s) {
     if (s->g_ready) return fail(ctx, YH_ERR_STATE, "yh_allgather_draw_lists_async: the communicator changed size under this scene");
     if (int rc = sync_scene(s)) return rc;
     const uint32_t F = s->desc.n_frusta;
+    // a set-up that failed half way (a rank with other frusta, out of memory) starts over
+    for (void** p : {(void**)&s->d_peer, (void**)&s->gmask, (void**)&s->send_pad, (void**)&s->gtile}) {
+        if (*p) HIP_TRY(ctx, hipFree(*p));
+        *p = nullptr;
+    }
+    if (s->ev_frame) HIP_TRY(ctx, hipEventDestroy(s->ev_frame));
+    s->ev_frame = nullptr;
+    for (hipEvent_t& e : s->ev_mask) {
+        if (e) HIP_TRY(ctx, hipEventDestroy(e));
+        e = nullptr;
+    }
     HIP_TRY(ctx, hipMalloc((void**)&s->d_peer, ((size_t)R + 1) * 16));
     const uint32_t mine[4] = {s->n_chunks, s->desc.id_base, F, 0u};
     HIP_TRY(ctx, hipMemcpy(s->d_peer + (size_t)R * 4, mine, 16, hipMemcpyHostToDevice));
