@@ -974,7 +974,8 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     a.ldirty = s->ldirty;
     a.wdirty = s->wdirty;
     a.bcount = s->counts + YH_MAX_FRUSTA * (1 + s->bset);
-    // visibility words: two sets once the no-sync gather is in use (the collective stream still sends the last frame's)
+    // visibility words and their byte counts: frames alternate between two sets (the previous frame's may still be
+    // waiting for its deferred expansion, or be on their way through the collective stream)
     uint64_t* words = s->vismask;
     uint8_t* byte_counts = s->viscnt;
     if (cull && s->mask_alt) {
