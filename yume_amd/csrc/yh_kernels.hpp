@@ -356,8 +356,10 @@ __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs(const FrameArgs a) {
     const uint32_t tile = xcd_tile(a, blockIdx.x);
     if (tile < a.n_tiles) frame_trs_tile<BOUNDS, HAS_BASE>(a, tile);
 }
+// (6 waves per SIMD: the chain kernels came out at 81-82 VGPRs, one over the 80 that allow a sixth wave; asking for it
+// costs no spill and gives cfg2 +2 %, the dominant launch 0.73 -> 0.76 of the HBM peak.  7 or 8 waves spill: -20..-30 %.)
 template <int G, int BOUNDS, bool HAS_BASE>
-__global__ __launch_bounds__(YH_BLOCK) void k_frame_chain(const FrameArgs a) {
+__global__ __launch_bounds__(YH_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void k_frame_chain(const FrameArgs a) {
     const uint32_t tile = xcd_tile(a, blockIdx.x);
     if (tile < a.n_tiles) frame_chain_tile<G, BOUNDS, HAS_BASE>(a, tile);
 }
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs_x(const FrameArgs a, con
     if (tile < a.n_tiles) frame_trs_tile<BOUNDS, false>(a, tile);
 }
 template <int G, int BOUNDS>
-__global__ __launch_bounds__(YH_BLOCK) void k_frame_chain_x(const FrameArgs a, const ExpandArgs x) {
+__global__ __launch_bounds__(YH_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void k_frame_chain_x(const FrameArgs a, const ExpandArgs x) {
     if (blockIdx.x < x.fuse_blocks) {
         expand_tile(x, blockIdx.x % x.n_tiles, blockIdx.x / x.n_tiles);
         return;
