@@ -186,7 +186,7 @@ def cpu_baseline_flecs(wl, lo_levels):
                       f"flecs 4.0.4 (TransformSyncSystem rule + both PostTransform sweeps, no cull; median)"}
 
 
-def kernel_symbol(levels_in_group, bounds, has_base, n_entities=1 << 40):
+def kernel_symbol(levels_in_group, bounds, has_base, n_entities=1 << 40, n_levels=8):
     """Name rocprofv3 reports for the launch of a level group (yume_hip.hip launch_trs / launch_chain / launch_first_x)."""
     hb = "true" if has_base else "false"
     if not has_base and n_entities <= 32 * 512 * 64:  # small scene: the first launch carries the previous frame's expansion
@@ -194,10 +194,12 @@ def kernel_symbol(levels_in_group, bounds, has_base, n_entities=1 << 40):
             return f"void k_frame_trs_x<{bounds}>(FrameArgs, ExpandArgs)"
         g = next(x for x in (2, 3, 4, 6, 8) if levels_in_group <= x)
         return f"void k_frame_chain_x<{g}, {bounds}>(FrameArgs, ExpandArgs)"
+    # scenes that outgrow the Infinity Cache use the variants with streaming input loads (YH_BIG_FLAT / YH_BIG_TREE)
+    big = n_entities >= ((5 << 20) if n_levels == 1 else (7 << 19))
     if levels_in_group == 1:
-        return f"void k_frame_trs<{bounds}, {hb}>(FrameArgs)"
+        return f"void k_frame_trs{'_big' if big else ''}<{bounds}, {hb}>(FrameArgs)"
     g = next(x for x in (2, 3, 4, 6, 8) if levels_in_group <= x)
-    return f"void k_frame_chain<{g}, {bounds}, {hb}>(FrameArgs)"
+    return f"void k_frame_chain{'_big' if big and g <= 3 else ''}<{g}, {bounds}, {hb}>(FrameArgs)"
 
 
 def profiled_traffic(workload, symbol):
@@ -364,7 +366,7 @@ def main():
         first, end = int(groups[g][2]), int(groups[g][3])
         b = algorithmic_bytes(wl, lo, parent, first, end, vis_sum)
         achieved = b / (ms[g] * 1e-3) / 1e9
-        sym = kernel_symbol(int(groups[g][1]) - int(groups[g][0]) + 1, wl["bounds"], int(groups[g][0]) > 0, n)
+        sym = kernel_symbol(int(groups[g][1]) - int(groups[g][0]) + 1, wl["bounds"], int(groups[g][0]) > 0, n, wl["levels"])
         traffic, traffic_src = profiled_traffic(args.workload, sym) if n == wl["n"] // (world_size if wl["scaling"] == "strong" else 1) else (None, None)
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

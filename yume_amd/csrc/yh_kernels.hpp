@@ -134,10 +134,10 @@ struct TrsInputs {
     uint32_t mesh;
 };
 
-template <int BOUNDS, bool NEED_PARENT, bool STREAM = false>
+template <int BOUNDS, bool NEED_PARENT, bool STREAM = false, bool STREAM_BOUNDS = false>
 __device__ __forceinline__ void load_inputs(const FrameArgs& a, uint32_t e, TrsInputs<BOUNDS>& in) {
     load_row<10, STREAM>(a.trs, e, in.t);
-    if (BOUNDS == 1) load_row<6, STREAM>(a.bounds, e, in.b);
+    if (BOUNDS == 1) load_row<6, STREAM || STREAM_BOUNDS>(a.bounds, e, in.b);
     in.mesh = (BOUNDS == 2) ? a.mesh_id[e] : 0u;
     in.pidx = NEED_PARENT ? a.parent[e] : 0u;
 }
@@ -266,7 +266,7 @@ __device__ __forceinline__ uint32_t xcd_tile(const FrameArgs& a, const uint32_t 
     return a.xcd_per ? (b & 7u) * a.xcd_per + (b >> 3) : b;
 }
 
-template <int BOUNDS, bool HAS_BASE>
+template <int BOUNDS, bool HAS_BASE, bool BIG = false>
 __device__ __forceinline__ void frame_trs_tile(const FrameArgs& a, const uint32_t tile) {
     const uint32_t tid = threadIdx.x;
     // chunk-aligned mapping: every wave covers exactly one 64-entity chunk of the arrays
@@ -276,7 +276,7 @@ __device__ __forceinline__ void frame_trs_tile(const FrameArgs& a, const uint32_
     // lanes outside [begin, end) redo a valid entity of the launch and store nothing
     const uint32_t e = e64 < a.begin ? a.begin : (e64 < a.end ? (uint32_t)e64 : a.end - 1u);
     TrsInputs<BOUNDS> in;
-    load_inputs<BOUNDS, HAS_BASE, true>(a, e, in);
+    load_inputs<BOUNDS, HAS_BASE, BIG>(a, e, in);  // read-once inputs: streamed only when the scene outgrows the cache
     M4 w;
     if (HAS_BASE) {
         load_row<16>(a.world, in.pidx, w.v);
@@ -301,7 +301,7 @@ __device__ __forceinline__ void frame_trs_tile(const FrameArgs& a, const uint32_
 // same order as level-by-level propagation, so the values are identical; the recomputation trades VALU work
 // and a dependent walk up the parent chain for G-1 fewer dependent launches.  Best for shallow groups of
 // small levels (the top of a tree), where a launch boundary costs more than the level's own traffic.
-template <int G, int BOUNDS, bool HAS_BASE>
+template <int G, int BOUNDS, bool HAS_BASE, bool BIG = false>
 __device__ __forceinline__ void frame_chain_tile(const FrameArgs& a, const uint32_t tile) {
     const uint32_t tid = threadIdx.x;
     const uint64_t e64 = (uint64_t)(a.begin & ~63u) + (uint64_t)tile * YH_BLOCK + tid;
@@ -309,7 +309,7 @@ __device__ __forceinline__ void frame_chain_tile(const FrameArgs& a, const uint3
     const bool valid = e64 >= a.begin && e64 < a.end;
     const uint32_t e = e64 < a.begin ? a.begin : (e64 < a.end ? (uint32_t)e64 : a.end - 1u);
     TrsInputs<BOUNDS> cur;
-    load_inputs<BOUNDS, true>(a, e, cur);
+    load_inputs<BOUNDS, true, false, BIG>(a, e, cur);
     // depth of e inside the group, and its ancestor chain: chain[0] = e, chain[j] = parent of chain[j-1]
     int d = 0;
 #pragma unroll
@@ -356,12 +356,28 @@ __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs(const FrameArgs a) {
     const uint32_t tile = xcd_tile(a, blockIdx.x);
     if (tile < a.n_tiles) frame_trs_tile<BOUNDS, HAS_BASE>(a, tile);
 }
+// Scenes that do not fit the 256 MB Infinity Cache stream their read-once inputs past it (nontemporal loads: 16M flat
+// entities 382 -> 367 us per frame); smaller scenes find their inputs still cached from the previous frame and are
+// 13-25 % FASTER with ordinary loads (4M flat: 99.8 -> 86.4 us, 1M: 24.9 -> 20.9, 500k: 13.5 -> 10.2).  The host picks.
+template <int BOUNDS, bool HAS_BASE>
+__global__ __launch_bounds__(YH_BLOCK) void k_frame_trs_big(const FrameArgs a) {
+    const uint32_t tile = xcd_tile(a, blockIdx.x);
+    if (tile < a.n_tiles) frame_trs_tile<BOUNDS, HAS_BASE, true>(a, tile);
+}
 // (6 waves per SIMD: the chain kernels came out at 81-82 VGPRs, one over the 80 that allow a sixth wave; asking for it
 // costs no spill and gives cfg2 +2 %, the dominant launch 0.73 -> 0.76 of the HBM peak.  7 or 8 waves spill: -20..-30 %.)
 template <int G, int BOUNDS, bool HAS_BASE>
 __global__ __launch_bounds__(YH_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void k_frame_chain(const FrameArgs a) {
     const uint32_t tile = xcd_tile(a, blockIdx.x);
     if (tile < a.n_tiles) frame_chain_tile<G, BOUNDS, HAS_BASE>(a, tile);
+}
+// The same for scenes that do not fit the 256 MB Infinity Cache: the bounds, read exactly once, are loaded
+// nontemporally (12.5M entities: 0.357 -> 0.342 ms per frame; at 1M entities, where a frame's whole working set
+// stays cached from one frame to the next, the same loads cost 6 %: the host picks by scene size).
+template <int G, int BOUNDS, bool HAS_BASE>
+__global__ __launch_bounds__(YH_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) void k_frame_chain_big(const FrameArgs a) {
+    const uint32_t tile = xcd_tile(a, blockIdx.x);
+    if (tile < a.n_tiles) frame_chain_tile<G, BOUNDS, HAS_BASE, true>(a, tile);
 }
 // The first launch of a frame (levels from 0: no stored base parent) with the PREVIOUS frame's expansion on board: the
 // launch's first x.fuse_blocks workgroups run expand_tile on the previous frame's words, the others are the frame's

@@ -42,6 +42,10 @@ struct LevelGroup {
 };
 
 #define YH_TIMING_RING 2048
+/* Entities from which a frame's inputs no longer stay in the 256 MB Infinity Cache from one frame to the next: larger
+   scenes stream their read-once inputs (measured crossovers: trees between 3M and 4M, flat scenes between 4M and 6M). */
+#define YH_BIG_TREE (7u << 19)
+#define YH_BIG_FLAT (5u << 20)
 #define YH_XCD_RUN 8u /* consecutive tiles one XCD takes in a tree launch */
 #define YH_MASK_SETS 2u /* sets of visibility words frames rotate through while a gather is in flight */
 #define YH_MASK_HALF 1u /* the frames' stream checks on the gather every YH_MASK_HALF-th frame (8 / 4 measured the same) */
@@ -886,23 +890,27 @@ struct LaunchEvents {
     } while (0)
 
 template <int BOUNDS>
-static void launch_trs(bool has_base, dim3 grid, hipStream_t st, LaunchEvents ev, const FrameArgs& a) {
-    if (has_base) YH_LAUNCH((k_frame_trs<BOUNDS, true>), grid, st, ev, a);
+static void launch_trs(bool has_base, dim3 grid, hipStream_t st, LaunchEvents ev, const FrameArgs& a, bool big) {
+    if (big && has_base) YH_LAUNCH((k_frame_trs_big<BOUNDS, true>), grid, st, ev, a);
+    else if (big) YH_LAUNCH((k_frame_trs_big<BOUNDS, false>), grid, st, ev, a);
+    else if (has_base) YH_LAUNCH((k_frame_trs<BOUNDS, true>), grid, st, ev, a);
     else YH_LAUNCH((k_frame_trs<BOUNDS, false>), grid, st, ev, a);
 }
 
 template <int BOUNDS, bool HAS_BASE>
-static void launch_chain_g(int G, dim3 grid, hipStream_t st, LaunchEvents ev, const FrameArgs& a) {
-    if (G <= 2) YH_LAUNCH((k_frame_chain<2, BOUNDS, HAS_BASE>), grid, st, ev, a);
+static void launch_chain_g(int G, dim3 grid, hipStream_t st, LaunchEvents ev, const FrameArgs& a, bool big) {
+    if (big && G <= 2) YH_LAUNCH((k_frame_chain_big<2, BOUNDS, HAS_BASE>), grid, st, ev, a);
+    else if (big && G <= 3) YH_LAUNCH((k_frame_chain_big<3, BOUNDS, HAS_BASE>), grid, st, ev, a);
+    else if (G <= 2) YH_LAUNCH((k_frame_chain<2, BOUNDS, HAS_BASE>), grid, st, ev, a);
     else if (G <= 3) YH_LAUNCH((k_frame_chain<3, BOUNDS, HAS_BASE>), grid, st, ev, a);
     else if (G <= 4) YH_LAUNCH((k_frame_chain<4, BOUNDS, HAS_BASE>), grid, st, ev, a);
     else if (G <= 6) YH_LAUNCH((k_frame_chain<6, BOUNDS, HAS_BASE>), grid, st, ev, a);
     else YH_LAUNCH((k_frame_chain<8, BOUNDS, HAS_BASE>), grid, st, ev, a);
 }
 template <int BOUNDS>
-static void launch_chain(int G, bool has_base, dim3 grid, hipStream_t st, LaunchEvents ev, const FrameArgs& a) {
-    if (has_base) launch_chain_g<BOUNDS, true>(G, grid, st, ev, a);
-    else launch_chain_g<BOUNDS, false>(G, grid, st, ev, a);
+static void launch_chain(int G, bool has_base, dim3 grid, hipStream_t st, LaunchEvents ev, const FrameArgs& a, bool big) {
+    if (has_base) launch_chain_g<BOUNDS, true>(G, grid, st, ev, a, big);
+    else launch_chain_g<BOUNDS, false>(G, grid, st, ev, a, big);
 }
 
 // First launch of a frame carrying the previous frame's expansion (levels from 0: no stored base parent).
@@ -1084,14 +1092,16 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
                     a.lvl_begin[j] = (g.lo + 1 + j <= g.hi) ? s->level_offsets[g.lo + 1 + j] : 0xFFFFFFFFu;
                 const dim3 grid = grid_for(a);
                 const int G = (int)(g.hi - g.lo + 1);
-                if (bounds == 0) launch_chain<0>(G, has_base, grid, st, ev, a);
-                else if (bounds == 1) launch_chain<1>(G, has_base, grid, st, ev, a);
-                else launch_chain<2>(G, has_base, grid, st, ev, a);
+                const bool big = s->n >= (uint64_t)YH_BIG_TREE;
+                if (bounds == 0) launch_chain<0>(G, has_base, grid, st, ev, a, big);
+                else if (bounds == 1) launch_chain<1>(G, has_base, grid, st, ev, a, big);
+                else launch_chain<2>(G, has_base, grid, st, ev, a, big);
             } else {
                 const dim3 grid = grid_for(a, s->desc.n_levels == 1);
-                if (bounds == 0) launch_trs<0>(has_base, grid, st, ev, a);
-                else if (bounds == 1) launch_trs<1>(has_base, grid, st, ev, a);
-                else launch_trs<2>(has_base, grid, st, ev, a);
+                const bool big = s->n >= (s->desc.n_levels == 1 ? (uint64_t)YH_BIG_FLAT : (uint64_t)YH_BIG_TREE);
+                if (bounds == 0) launch_trs<0>(has_base, grid, st, ev, a, big);
+                else if (bounds == 1) launch_trs<1>(has_base, grid, st, ev, a, big);
+                else launch_trs<2>(has_base, grid, st, ev, a, big);
             }
             HIP_TRY(ctx, hipGetLastError());
             ++launches;
