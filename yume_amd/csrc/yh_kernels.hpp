@@ -58,7 +58,7 @@ __host__ __device__ __forceinline__ uint64_t eoff(uint32_t e) {
 template <bool STREAM = false>
 __device__ __forceinline__ float lde(const float* __restrict__ base, uint64_t off, int q) {
     const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off + q * 256);
-    if (STREAM) return __builtin_nontemporal_load(p);  // read-once inputs of a single-level launch (measured +2 %)
+    if (STREAM) return __builtin_nontemporal_load(p);  // read-once inputs of a scene too large for the Infinity Cache
     return *p;
 }
 // World matrices are written once per frame and read back at most by the next level: streaming (nontemporal)
