@@ -410,7 +410,7 @@ __global__ __launch_bounds__(YH_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) v
 // TransformSyncSystem.zig:60-73, one level per launch (the parent's dirty flag must already be this
 // frame's), followed by the culling stage.  The dirty reset of PostTransformSystem.zig:31-35 is done by
 // k_clear_dirty after the last level.
-template <int BOUNDS, bool HAS_BASE>
+template <int BOUNDS, bool HAS_BASE, bool BIG>  // BIG: the scene outgrows the Infinity Cache, read-once rows are streamed
 __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, const uint32_t root_dirty) {
     const uint32_t tid = threadIdx.x;
     const uint32_t tile = xcd_tile(a, blockIdx.x);
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, cons
             a.wdirty[e] = 1;  // :65
             if (ld || pd) {   // :67-68
                 M4 l;
-                load_row<16>(a.lmat, e, l.v);
+                load_row<16, BIG>(a.lmat, e, l.v);
                 w = m4_mul(pm, l);
                 store_row<16>(a.world, e, w.v);
             } else {  // :69-72 world-edited entity: re-derive the local matrix
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, cons
         if (BOUNDS != 0) {
             float b[6] = {0, 0, 0, 0, 0, 0};
             uint32_t mesh = 0;
-            if (BOUNDS == 1) load_row<6>(a.bounds, e, b);
+            if (BOUNDS == 1) load_row<6, BIG>(a.bounds, e, b);
             else mesh = a.mesh_id[e];
             cull_entity<BOUNDS>(a, w, b, mesh, vmask, bmask);
         }

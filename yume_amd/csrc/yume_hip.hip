@@ -939,12 +939,11 @@ static void launch_chain_mat4(int G, bool has_base, dim3 grid, hipStream_t st, c
 }
 
 template <int BOUNDS>
-static void launch_mat4(bool has_base, dim3 grid, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
-    if (has_base) {
-        hipLaunchKernelGGL((k_level_mat4<BOUNDS, true>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
-    } else {
-        hipLaunchKernelGGL((k_level_mat4<BOUNDS, false>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
-    }
+static void launch_mat4(bool has_base, bool big, dim3 grid, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
+    if (has_base && big) hipLaunchKernelGGL((k_level_mat4<BOUNDS, true, true>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
+    else if (has_base) hipLaunchKernelGGL((k_level_mat4<BOUNDS, true, false>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
+    else if (big) hipLaunchKernelGGL((k_level_mat4<BOUNDS, false, true>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
+    else hipLaunchKernelGGL((k_level_mat4<BOUNDS, false, false>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
 }
 
 static int ensure_kev(yh_scene* s) {
@@ -1124,9 +1123,10 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
                 else if (bounds == 1) launch_chain_mat4<1>(G, has_base, grid, st, a, s->root_dirty);
                 else launch_chain_mat4<2>(G, has_base, grid, st, a, s->root_dirty);
             } else {
-                if (bounds == 0) launch_mat4<0>(has_base, grid, st, a, s->root_dirty);
-                else if (bounds == 1) launch_mat4<1>(has_base, grid, st, a, s->root_dirty);
-                else launch_mat4<2>(has_base, grid, st, a, s->root_dirty);
+                const bool big = s->n >= (uint64_t)YH_BIG_TREE;  // 12.5M columns, all dirty: 452 -> 417 us with streamed locals and bounds
+                if (bounds == 0) launch_mat4<0>(has_base, big, grid, st, a, s->root_dirty);
+                else if (bounds == 1) launch_mat4<1>(has_base, big, grid, st, a, s->root_dirty);
+                else launch_mat4<2>(has_base, big, grid, st, a, s->root_dirty);
             }
             HIP_TRY(ctx, hipGetLastError());
             if (int rc = time_end()) return rc;
