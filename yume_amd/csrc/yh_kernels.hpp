@@ -138,8 +138,9 @@ template <int BOUNDS, bool NEED_PARENT, bool STREAM = false, bool STREAM_BOUNDS 
 __device__ __forceinline__ void load_inputs(const FrameArgs& a, uint32_t e, TrsInputs<BOUNDS>& in) {
     load_row<10, STREAM>(a.trs, e, in.t);
     if (BOUNDS == 1) load_row<6, STREAM || STREAM_BOUNDS>(a.bounds, e, in.b);
-    in.mesh = (BOUNDS == 2) ? a.mesh_id[e] : 0u;
-    in.pidx = NEED_PARENT ? a.parent[e] : 0u;
+    constexpr bool S = STREAM || STREAM_BOUNDS;  // read-once indices of a scene too large for the caches
+    in.mesh = (BOUNDS == 2) ? (S ? __builtin_nontemporal_load(a.mesh_id + e) : a.mesh_id[e]) : 0u;
+    in.pidx = NEED_PARENT ? (S ? __builtin_nontemporal_load(a.parent + e) : a.parent[e]) : 0u;
 }
 
 // ---- stage 3 back end, part 2: prefix sums + expansion into ordered draw lists -----------------------------
