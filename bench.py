@@ -189,7 +189,7 @@ def cpu_baseline_flecs(wl, lo_levels):
 def kernel_symbol(levels_in_group, bounds, has_base, n_entities=1 << 40, n_levels=8):
     """Name rocprofv3 reports for the launch of a level group (yume_hip.hip launch_trs / launch_chain / launch_first_x)."""
     hb = "true" if has_base else "false"
-    if not has_base and n_entities <= 32 * 512 * 64:  # small scene: the first launch carries the previous frame's expansion
+    if not has_base and n_entities <= 64 * 1024 * 64:  # up to 1024 expand tiles: the first launch carries the previous frame's expansion
         if levels_in_group == 1:
             return f"void k_frame_trs_x<{bounds}>(FrameArgs, ExpandArgs)"
         g = next(x for x in (2, 3, 4, 6, 8) if levels_in_group <= x)

@@ -351,7 +351,7 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
     s->n_chunks = (uint32_t)(S / YH_CHUNK);
     // expand tiles: 32 words (2048 entities) while that still fits the self-counting path (1M entities: 39.8 vs 40.6 us
     // per frame), 64 words keep mid-size scenes parallel, 256 words beyond 8M entities (all measured)
-    s->tile_words = s->n_chunks <= 32u * (uint32_t)YH_SELF_COUNT_TILES ? 32u
+    s->tile_words = s->n_chunks <= 32u * 512u ? 32u
                     : s->n_chunks <= 32u * 4096u                       ? 64u
                                                                        : (uint32_t)YH_EXPAND_WORDS_MAX;
     s->n_tiles = (s->n_chunks + s->tile_words - 1) / s->tile_words;
