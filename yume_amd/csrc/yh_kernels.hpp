@@ -151,7 +151,7 @@ __device__ __forceinline__ void load_inputs(const FrameArgs& a, uint32_t e, TrsI
 // is the sum of the tile counts before it (read redundantly: a few thousand L2-resident words, cheaper than a
 // dependent scan launch), the tile's words are prefix-summed through LDS and the 4 waves expand them
 // round-robin, one word per step: lane l emits entity chunk*64+l at rank mbcnt(word).  Ascending entity order,
-// coalesced stores, no atomics.  Scenes of at most YH_SELF_COUNT_TILES tiles (4M entities) skip k_count: the frame
+// coalesced stores, no atomics.  Scenes of at most YH_SELF_COUNT_TILES tiles of at most 64 words (4M entities) skip k_count: the frame
 // kernels store each word's popcount as a byte next to it, and every expand workgroup adds up the bytes before its
 // tile itself (16 per load, v_dot4: at most 64 KiB of L2-resident bytes) — one dependent launch less per frame, and
 // the expansion can ride on the next frame's first launch (4M flat: 86.5 -> 79.1 us; 2048 tiles: worse at 8M).

@@ -452,7 +452,7 @@ static int plan_groups(yh_scene* s) {
     // lighter first launch once they need a second one anyway: 1M entities 34.5 us for 0..4 | 5..7 against 35.1 for
     // 0..5 | 6..7, 500k 22.2 us for 0..5 | 6..7 against 23.4 for 0..6 | 7; a 250k scene stays one launch (13.9 us).
     const bool rides = s->desc.local_kind == YH_LOCAL_TRS && s->desc.bounds_kind != YH_BOUNDS_NONE &&
-                       s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES && s->n > 320 * 1024;
+                       (s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES && s->tile_words <= 64u) && s->n > 320 * 1024;
     uint32_t lo = 0;
     while (lo < L) {
         const uint64_t resident = (lo == 0 && rides) ? 128 * 1024 : 320 * 1024;
@@ -1152,7 +1152,7 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
             c.n_chunks = s->n_chunks;
             c.n_tiles = s->n_tiles;
             c.words = s->tile_words;
-            c.self_count = s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES;
+            c.self_count = (s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES && s->tile_words <= 64u);
             if (!c.self_count) hipLaunchKernelGGL(k_count, dim3(s->n_tiles, 1), dim3(YH_BLOCK), 0, st, c);
             hipLaunchKernelGGL(k_expand, dim3(s->n_tiles, 1), dim3(YH_BLOCK), 0, st, c);
             HIP_TRY(ctx, hipGetLastError());
@@ -1190,7 +1190,7 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         x.n_tiles = s->n_tiles;
         x.words = s->tile_words;
         x.id_base = s->desc.id_base;
-        x.self_count = s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES;
+        x.self_count = (s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES && s->tile_words <= 64u);
         if (int rc = time_begin(YH_MAX_LEVELS - 1)) return rc;
         if (!x.self_count) {
             hipLaunchKernelGGL(k_count, dim3(s->n_tiles, n_frusta), dim3(YH_BLOCK), 0, st, x);
