@@ -49,7 +49,7 @@ FRAMES_IN_FLIGHT = 256
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=800)
+    ap.add_argument("--steps", type=int, default=1600)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--entities", type=int, default=0, help="override entities per GPU")
@@ -335,12 +335,12 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # timed region: K frames; on every (K / 25)-th frame, between every 4th and every 32nd (25 samples at the default
-    # K = 800: an instrumented frame costs the stream ~20 us, 1-2 % of `value` at that rate), the
-    # transform launches carry a pair of HIP events each (hipExtLaunchKernelGGL on the library's stream: the dispatch's own start/end timestamps, the
-    # ones rocprofv3's kernel trace reports; nothing is added to the stream).  All transform launches of a sampled
+    # timed region: K frames; on every (K / 25)-th frame, between every 4th and every 64th (25 samples at the default
+    # K = 1600: an instrumented frame costs the stream ~20 us, 1-2 % of `value` at that rate), the
+    # transform launches carry a pair of HIP events each (hipExtLaunchKernelGGL on the library's stream: the dispatch's
+    # own start/end timestamps, the ones rocprofv3's kernel trace reports; nothing is added to the stream).  All transform launches of a sampled
     # frame, not just the dominant one: a launch whose predecessor is not instrumented reads ~3 us long.
-    period = max(4, min(32, args.steps // 25))
+    period = max(4, min(64, args.steps // 25))
     if not args.no_kernel_events:
         scene.set_kernel_timing(-1, period)
     t0 = time.perf_counter()
