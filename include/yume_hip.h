@@ -152,6 +152,22 @@ int yh_upload_mesh_ids(yh_scene* s, const uint32_t* mesh_id, uint64_t first, uin
  * callbacks (Editor.zig:301-306).                                                                        */
 int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uint32_t flags);
 
+/* yh_frame for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for hosts that may not call
+ * hipMalloc around the frame — code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same arguments, same launches and the same results as yh_frame (world matrices, draw lists, counts and boundary
+ * counts land in the scene's buffers and are read with the same yh_get_ / yh_download_ calls); the frame's stage-3
+ * scratch (boundary counters, tile counts, visibility words, their byte counts) lies in a file-scope device array of
+ * YH_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends, so the call makes no
+ * hipMalloc / hipFree / event creation (kernel-timing events are not recorded on this path, nothing is deferred to a
+ * later call).  Limit: n_frusta x (9 bytes per 64 entities + 4 per expand tile) + 144 <= YH_STATIC_SCRATCH_BYTES,
+ * about 119M entity-frusta (16M entities x 7 frusta); beyond it YH_ERR_CAPACITY and nothing is launched.  All calls on
+ * one GPU share that GPU's array (it keeps the last call's contents; the call clears what must start at zero): calls
+ * on ONE context are ordered by its stream, calls on two contexts of the same GPU that overlap RACE.  The words of
+ * such a frame cannot be sent by yh_allgather_draw_lists_async afterwards (YH_ERR_STATE); the synchronous
+ * yh_allgather_draw_lists works.                                                                            */
+#define YH_STATIC_SCRATCH_BYTES (16u << 20)
+int yh_frame_static(yh_scene* s, const float* planes, uint32_t n_frusta, uint32_t flags);
+
 /* Results.  counts/boundary: n_frusta entries.  A "boundary" entity has |s + r| < 1e-5 for some plane. */
 int yh_get_counts(yh_scene* s, uint32_t* counts, uint32_t* boundary_counts);
 /* Copies draw list `frustum` to `out`; *written = entries of the list.  If cap is too small returns

@@ -14,6 +14,7 @@ YH_MAX_FRUSTA = 8
 YH_MAX_LEVELS = 64
 YH_NO_PARENT = 0xFFFFFFFF
 YH_UNIQUE_ID_BYTES = 128
+YH_STATIC_SCRATCH_BYTES = 16 << 20
 
 YH_OK = 0
 YH_ERR_BAD_ARG = -1
@@ -98,6 +99,7 @@ SIGNATURES = {
     "yh_upload_mesh_aabbs": (_int, [_vp, _vp, _u32]),
     "yh_upload_mesh_ids": (_int, [_vp, _vp, _u64, _u64]),
     "yh_frame": (_int, [_vp, _vp, _u32, _u32]),
+    "yh_frame_static": (_int, [_vp, _vp, _u32, _u32]),
     "yh_get_counts": (_int, [_vp, _vp, _vp]),
     "yh_get_draw_list": (_int, [_vp, _u32, _vp, _u64, C.POINTER(_u64)]),
     "yh_download_world_soa": (_int, [_vp, _vp, _u64, _u64]),

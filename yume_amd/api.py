@@ -190,6 +190,17 @@ class Scene:
         self._ck(L.lib().yh_frame(self._h, _ptr(planes), planes.shape[0], flags))
         self._last_frusta = 0 if flags & L.YH_FRAME_NO_CULL else planes.shape[0]
 
+    def frame_static(self, planes=None, flags=L.YH_FRAME_ALL_DIRTY):
+        """yh_frame_static: the same frame with its stage-3 scratch in the library's static device array (allocates
+        nothing).  Results are read exactly as after frame()."""
+        if planes is None:
+            self._ck(L.lib().yh_frame_static(self._h, None, 0, flags))
+            self._last_frusta = 0
+            return
+        planes = np.ascontiguousarray(planes, np.float32).reshape(-1, 24)
+        self._ck(L.lib().yh_frame_static(self._h, _ptr(planes), planes.shape[0], flags))
+        self._last_frusta = 0 if flags & L.YH_FRAME_NO_CULL else planes.shape[0]
+
     def counts(self):
         c = np.zeros(L.YH_MAX_FRUSTA, np.uint32)
         b = np.zeros(L.YH_MAX_FRUSTA, np.uint32)

@@ -30,6 +30,7 @@ struct yh_ctx {
     std::vector<struct yh_scene*> scenes;  // live scenes of this context (yh_wait flushes their deferred expansions)
     hipStream_t stream_c = nullptr;  // collectives of the no-host-sync gather (created by yh_comm_init)
     hipDeviceProp_t prop{};
+    unsigned char* scratch_ptr = nullptr;  // this device's copy of the file-scope `scratch` array (yh_frame_static)
     std::string err;
     // RCCL (optional)
     void* rccl_lib = nullptr;
@@ -155,6 +156,13 @@ struct yh_scene {
 
 static int flush_expand(yh_scene* s);
 
+// Stage-3 scratch of yh_frame_static (the entry point that allocates nothing): boundary counters, tile counts,
+// visibility words and their byte counts of ONE frame.  Every GPU the library runs on holds its own copy of the array
+// at its own address until the process ends; `scratch` itself is only a host-side stand-in for the symbol, so host
+// code never passes it anywhere: yh_init looks the device address up once per context (hipGetSymbolAddress, with
+// that device current) and everything afterwards uses yh_ctx::scratch_ptr.
+static __device__ __align__(256) unsigned char scratch[YH_STATIC_SCRATCH_BYTES];
+
 static thread_local std::string g_err;
 
 static int fail(yh_ctx* ctx, int code, const char* fmt, ...) {
@@ -206,6 +214,8 @@ extern "C" int yh_init(int device_id, yh_ctx** out) {
     // shared queue holds back everything behind it (a gather stream created after RCCL's own landed on the frames'
     // queue and serialised the exchange with the frames: 50 -> 69 us per cfg2 frame).
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipGetSymbolAddress((void**)&c->scratch_ptr, HIP_SYMBOL(scratch));  // device `device_id` is current
+    if (e == hipSuccess && !c->scratch_ptr) e = hipErrorInvalidSymbol;
     for (hipStream_t st : {c->stream, c->stream_c}) {
         hipEvent_t touch = nullptr;
         if (e == hipSuccess) e = hipEventCreateWithFlags(&touch, hipEventDisableTiming);
@@ -954,8 +964,25 @@ static int ensure_kev(yh_scene* s) {
     return YH_OK;
 }
 
-extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uint32_t flags) {
-    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_frame: scene is NULL");
+// Where the stage-3 scratch of one frame lies inside the static array (yh_frame_static): 32 counter words (only
+// [8, 24) are used: the boundary counters and the set k_expand zeroes), tile counts, visibility words, byte counts.
+struct StaticLayout {
+    uint64_t tilecnt_off, words_off, cnt_off, bytes;
+};
+static StaticLayout static_layout(const yh_scene* s, uint32_t n_frusta) {
+    const uint64_t F = n_frusta ? n_frusta : 1;
+    StaticLayout l;
+    l.tilecnt_off = 4 * YH_MAX_FRUSTA * 4;
+    l.words_off = l.tilecnt_off + ((F * s->n_tiles + 1) & ~1ull) * 4;
+    l.cnt_off = (l.words_off + F * s->n_chunks * 8 + 15) & ~15ull;
+    l.bytes = l.cnt_off + F * s->cnt_stride;
+    return l;
+}
+
+// One frame.  use_static: the stage-3 scratch lies in the context's copy of the static array instead of the scene's
+// own buffers, nothing is deferred to a later call, and no event or buffer is created (yh_frame_static).
+static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint32_t flags, const bool use_static, const char* who) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "%s: scene is NULL", who);
     yh_ctx* ctx = s->ctx;
     if (!s->have_hierarchy) return fail(ctx, YH_ERR_STATE, "yh_frame: call yh_upload_hierarchy first");
     const bool cull = !(flags & YH_FRAME_NO_CULL) && s->desc.bounds_kind != YH_BOUNDS_NONE && n_frusta > 0;
@@ -969,6 +996,22 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         return fail(ctx, YH_ERR_UNSUPPORTED, "yh_frame: TRS scenes recompute every entity; pass YH_FRAME_ALL_DIRTY");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    StaticLayout sl{};
+    unsigned char* const sp = ctx->scratch_ptr;  // the device address of this GPU's copy, never the array's name
+    if (use_static) {
+        if (!sp) return fail(ctx, YH_ERR_STATE, "%s: the static scratch array was not resolved at yh_init", who);
+        sl = static_layout(s, cull ? n_frusta : 0);
+        if (cull && sl.bytes > (uint64_t)YH_STATIC_SCRATCH_BYTES)
+            return fail(ctx, YH_ERR_CAPACITY,
+                        "%s: %llu entities x %u frusta need %llu bytes of stage-3 scratch, the static array holds %llu "
+                        "(about 119M entity-frusta); use yh_frame",
+                        who, (unsigned long long)s->n, n_frusta, (unsigned long long)sl.bytes, (unsigned long long)YH_STATIC_SCRATCH_BYTES);
+        if (int rc = flush_expand(s)) return rc;  // an expansion a deferred frame left behind: launch it now (no allocation)
+        // the array keeps the previous call's contents: the boundary counters must start at zero, everything else
+        // (tile counts, words, byte counts) is fully rewritten by this frame's launches before it is read
+        if (cull) HIP_TRY(ctx, hipMemsetAsync(sp, 0, 4 * YH_MAX_FRUSTA * 4, st));
+    }
+    const bool ktiming = s->kernel_timing && !use_static;  // per-launch events are created lazily: not here
 
     FrameArgs a;
     memset(&a, 0, sizeof a);
@@ -985,7 +1028,11 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     // waiting for its deferred expansion, or be on their way through the collective stream)
     uint64_t* words = s->vismask;
     uint8_t* byte_counts = s->viscnt;
-    if (cull && s->mask_alt) {
+    if (use_static) {
+        a.bcount = (uint32_t*)sp + YH_MAX_FRUSTA;
+        words = (uint64_t*)(sp + sl.words_off);
+        byte_counts = sp + sl.cnt_off;
+    } else if (cull && s->mask_alt) {
         const uint32_t p = s->mparity;
         if (p % YH_MASK_HALF == 0) {  // about to rewrite sets p .. p+HALF-1: the latest gather that sent one of them
             int latest = -1;          // must be done (the collective stream runs in order, so the earlier ones are too)
@@ -1028,15 +1075,15 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         return dim3((fa.n_tiles + 8u * YH_XCD_RUN - 1u) / (8u * YH_XCD_RUN) * (8u * YH_XCD_RUN));
     };
 
-    const bool frame_events = s->kernel_timing && s->timing_only == -1 && (s->frames % s->timing_period == 0);
+    const bool frame_events = ktiming && s->timing_only == -1 && (s->frames % s->timing_period == 0);
     if (frame_events) HIP_TRY(ctx, hipEventRecord(s->ev0, st));
     uint32_t launches = 0;
-    if (s->kernel_timing)
+    if (ktiming)
         if (int rc = ensure_kev(s)) return rc;
 
     bool timing_this = false;
     auto time_begin = [&](uint32_t group) -> int {
-        timing_this = s->kernel_timing && s->kev_used < YH_TIMING_RING && (s->timing_only == -1 || s->timing_only == (int)group) &&
+        timing_this = ktiming && s->kev_used < YH_TIMING_RING && (s->timing_only == -1 || s->timing_only == (int)group) &&
                       (s->frames % s->timing_period == 0);
         if (timing_this) {
             s->kev_group[s->kev_used] = group;
@@ -1054,7 +1101,7 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     // single-kernel groups: the event pair rides on the launch instead
     auto time_launch = [&](uint32_t group) -> LaunchEvents {
         LaunchEvents ev;
-        if (s->kernel_timing && s->kev_used < YH_TIMING_RING && (s->timing_only < 0 || (uint32_t)s->timing_only == group) &&
+        if (ktiming && s->kev_used < YH_TIMING_RING && (s->timing_only < 0 || (uint32_t)s->timing_only == group) &&
             (s->frames % s->timing_period == 0)) {
             s->kev_group[s->kev_used] = group;
             ev.start = s->kev[2 * s->kev_used];
@@ -1171,19 +1218,26 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         ExpandArgs x;
         memset(&x, 0, sizeof x);
         x.vismask = words;
-        s->last_mask = words;
-        s->last_mparity = s->mparity;
-        if (s->mask_alt) s->mparity = (s->mparity + 1u) % YH_MASK_SETS;
         x.viscnt = byte_counts;
         x.cnt_stride = s->cnt_stride;
-        x.tilecnt = s->tilecnt;
         x.counts = s->counts;
-        // three sets of boundary counters: this frame's, the next frame's (its launches may already be adding to it
-        // when a deferred expansion runs) and the one after, which this expansion zeroes
-        x.bcount_cur = s->counts + YH_MAX_FRUSTA * (1 + s->bset);
-        x.bcount_next = s->counts + YH_MAX_FRUSTA * (1 + (s->bset + 2u) % 3u);
         x.host_counts = s->h_counts_dev;
-        s->bset = (s->bset + 1u) % 3u;
+        if (use_static) {
+            s->last_mask = nullptr;  // these words are gone with the next call on this GPU: nothing may send them later
+            x.tilecnt = (uint32_t*)(sp + sl.tilecnt_off);
+            x.bcount_cur = (uint32_t*)sp + YH_MAX_FRUSTA;
+            x.bcount_next = (uint32_t*)sp + 2 * YH_MAX_FRUSTA;
+        } else {
+            s->last_mask = words;
+            s->last_mparity = s->mparity;
+            if (s->mask_alt) s->mparity = (s->mparity + 1u) % YH_MASK_SETS;
+            x.tilecnt = s->tilecnt;
+            // three sets of boundary counters: this frame's, the next frame's (its launches may already be adding to
+            // it when a deferred expansion runs) and the one after, which this expansion zeroes
+            x.bcount_cur = s->counts + YH_MAX_FRUSTA * (1 + s->bset);
+            x.bcount_next = s->counts + YH_MAX_FRUSTA * (1 + (s->bset + 2u) % 3u);
+            s->bset = (s->bset + 1u) % 3u;
+        }
         for (uint32_t f = 0; f < YH_MAX_FRUSTA; ++f) x.draw[f] = s->draw[f];
         x.draw_cap = s->draw_cap;
         x.n_chunks = s->n_chunks;
@@ -1203,8 +1257,8 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
         // large scenes keep k_expand: riding on their one big launch costs that kernel more than the boundary.
         const bool small_first = !s->groups.empty() && s->groups.size() > 1 &&
                                  s->level_offsets[s->groups[0].hi + 1] - s->level_offsets[0] <= 320u * 1024u;
-        const bool defer = (flags & YH_FRAME_ASYNC) && s->desc.local_kind == YH_LOCAL_TRS &&
-                           (x.self_count || small_first) && !(s->kernel_timing && s->timing_only == -1);
+        const bool defer = !use_static && (flags & YH_FRAME_ASYNC) && s->desc.local_kind == YH_LOCAL_TRS &&
+                           (x.self_count || small_first) && !(ktiming && s->timing_only == -1);
         if (defer) {
             s->pend = x;
             s->pend_frusta = n_frusta;
@@ -1224,6 +1278,17 @@ extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uin
     ++s->frames;
     if (!(flags & YH_FRAME_ASYNC)) return sync_scene(s);
     return YH_OK;
+}
+
+extern "C" int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uint32_t flags) {
+    return frame_impl(s, planes, n_frusta, flags, false, "yh_frame");
+}
+
+// yh_frame for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid it): the same
+// launches, the stage-3 scratch in this GPU's copy of the file-scope `scratch` array.  No hipMalloc / hipFree /
+// event creation on this path; hipMemsetAsync and the launches take the device address kept in the context.
+extern "C" int yh_frame_static(yh_scene* s, const float* planes, uint32_t n_frusta, uint32_t flags) {
+    return frame_impl(s, planes, n_frusta, flags, true, "yh_frame_static");
 }
 
 extern "C" int yh_get_counts(yh_scene* s, uint32_t* counts, uint32_t* boundary_counts) {

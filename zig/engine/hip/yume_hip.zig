@@ -61,6 +61,10 @@ pub extern fn yh_download_changed_aos68(s: *Scene, slots: ?[*]u32, world_rows: ?
 pub extern fn yh_mark_dirty(s: *Scene, local: c_int, world: c_int, first: u64, count: u64) c_int;
 pub extern fn yh_upload_aabb(s: *Scene, min_planes: *const [3][*]const f32, max_planes: *const [3][*]const f32, first: u64, count: u64) c_int;
 pub extern fn yh_frame(s: *Scene, planes: ?[*]const f32, n_frusta: u32, flags: u32) c_int;
+/// yh_frame for hosts that may not allocate around the frame (no counterpart in the reference): same results,
+/// stage-3 scratch in the library's static device array (16 MiB per GPU), `capacity` beyond ~119M entity-frusta.
+pub const static_scratch_bytes: u32 = 16 << 20;
+pub extern fn yh_frame_static(s: *Scene, planes: ?[*]const f32, n_frusta: u32, flags: u32) c_int;
 pub extern fn yh_get_counts(s: *Scene, counts: [*]u32, boundary_counts: ?[*]u32) c_int;
 pub extern fn yh_get_draw_list(s: *Scene, frustum: u32, out: [*]u32, cap: u64, written: *u64) c_int;
 pub extern fn yh_download_world_aos68(s: *Scene, column: *anyopaque, first: u64, count: u64) c_int;
