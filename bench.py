@@ -7,16 +7,20 @@ over one synthetic scene that is already resident in HBM.  One process per GPU:
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workloads (BASELINE.json configs): cfg2 (default; 1M entities, random 8-level tree, 1 frustum, per GPU),
-cfg3 (16M flat, 5 frusta), cfg4 (12.5M-entity 8-level shard per GPU = 100M on 8), cfg5 (256M flat instanced
-AABBs, split over the GPUs).  With N > 1 every rank owns a subtree-closed shard (its own tree, global ids
-offset by shard_base) and each frame ends with the RCCL all-gather of counts and draw lists.  Scaling is
-weak for cfg2/cfg3/cfg4 (per-GPU shard fixed) and strong for cfg5.
+The headline (`value`, `ms_per_step`, `roofline`) is the largest single-GPU configuration of BASELINE.json, cfg5:
+256M flat instances with instanced AABBs — 29 GB of arrays, far outside the 256 MB Infinity Cache, ~4.7 ms per frame,
+so K = 20 steps are ~95 ms of GPU time.  With N > 1 its instances are split over the GPUs (strong scaling) and each
+frame ends with the all-gather of the draw lists.  The other GPU configurations run right after it as sub-records
+of the same JSON line (`workloads`: cfg2 = 1M entities / 8 levels, cfg3 = 16M flat x 5 frusta, cfg4 = the 12.5M-entity
+shard one GPU holds of the 100M-entity scene), each timed over at least 50 ms of frames, each with its own roofline
+object.  `--workload cfgN` makes another configuration the headline; `--no-sub` drops the sub-records.
 """
 import argparse
 import json
+import math
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -26,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+INFINITY_CACHE_BYTES = 256 << 20
 
 WORKLOADS = {
     # name: (entities per GPU or total, levels, frusta, bounds_kind, scaling)
@@ -38,7 +43,10 @@ WORKLOADS = {
     "cfg5": dict(n=256 * 1000 * 1000, levels=1, frusta="main", bounds=2, scaling="strong",
                  desc="256M flat instances, 16 instanced AABBs, split over the GPUs (BASELINE configs[4])"),
 }
-
+SUB_ORDER = ("cfg2", "cfg3", "cfg4", "cfg5")
+SUB_MIN_TIMED_S = 0.060   # every sub-record times at least this much GPU work
+SUB_BUDGET_S = 240.0      # no further sub-record is started after this many seconds of sub-records
+WATCHDOG_S = 420.0        # hard limit on the sub-records: the headline line is printed without the missing ones
 
 # Frames enqueued before the host waits for the device once (inside the timed region: it is part of the cost).  Without
 # a bound the HIP runtime's command and kernel-argument pools run dry after ~1000 un-synchronised launches and the
@@ -49,42 +57,45 @@ FRAMES_IN_FLIGHT = 256
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1600)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--entities", type=int, default=0, help="override entities per GPU")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg5", choices=sorted(WORKLOADS), help="the headline configuration")
+    ap.add_argument("--no-sub", action="store_true", help="headline only: no sub-records of the other configurations")
+    ap.add_argument("--sub", default="", help="comma-separated sub-records to run (default: every other configuration)")
+    ap.add_argument("--entities", type=int, default=0, help="override the headline's entities per GPU")
     ap.add_argument("--grouping", type=int, default=0, help="levels per launch (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-comm", action="store_true",
                     help="rehearsal on one GPU: bring up a one-rank RCCL communicator and run the multi-GPU step "
                          "(frame + pipelined all-gather) - measures what the exchange adds to a frame")
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not hand HIP events to the launches")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-def algorithmic_bytes(wl, lo, parent, first, end, visible_per_entity_sum):
-    """compulsory HBM bytes of a fully fused pass over entities [first, end).
-    reads: TRS 40 B + parent index 4 B (levels > 0) + AABB 24 B (or 4 B mesh id) + 64 B per DISTINCT parent per
-    level; writes: world 64 B + 4 B per emitted draw index."""
-    from yume_amd import synth
-
+def algorithmic_bytes(wl, lo, parent, first, end, n_frusta, list_entries):
+    """Compulsory HBM bytes of a fully fused pass over entities [first, end).
+    Returns (own, lists):
+      own   = what the TRANSFORM launch itself has to move: reads TRS 40 B + parent index 4 B (levels > 0) + AABB 24 B
+              (or 4 B mesh id) + 64 B per DISTINCT parent per level; writes world 64 B + one visibility bit per entity
+              and frustum and one count byte per 64 (the launch's stage-3 output);
+      lists = 4 B per emitted draw index — written by k_expand (or by the next frame's fused first launch), so they
+              are charged to the frame and to the expansion, never to the transform launch."""
     n = end - first
     b = n * (40 + 64) + n * (24 if wl["bounds"] == 1 else 4)
     n_child = end - max(first, int(lo[1]))
     if n_child > 0:
         b += 4 * n_child
-        # distinct parents of the levels that intersect [first, end)
-        for k in range(1, len(lo) - 1):
+        for k in range(1, len(lo) - 1):  # distinct parents of the levels that intersect [first, end)
             a, z = max(first, int(lo[k])), min(end, int(lo[k + 1]))
             if z > a:
                 p = parent[a:z]
                 b += 64 * int(np.count_nonzero(np.diff(p)) + 1)
-    b += 4 * visible_per_entity_sum * n
-    return float(b)
+    b += n_frusta * (n / 8.0 + n / 64.0)
+    return float(b), 4.0 * float(list_entries)
 
 
-def cpu_baseline(args, wl, n, lo, parent, planes, seconds):
+def cpu_baseline(wl, n, lo, parent, planes, seconds):
     """The reference CPU systems (oracle port: AoS 68-byte columns, one batch per table, forward branch on every
     row + both dirty sweeps, then the cull), single thread as the reference runs them, on the host cores of
     this box.  Only this leg touches oracle/."""
@@ -135,20 +146,22 @@ def cpu_baseline(args, wl, n, lo, parent, planes, seconds):
     return out
 
 
-def cpu_baseline_flecs(wl, lo_levels):
+def cpu_baseline_flecs(lo_levels):
     """The same rule driven by the REAL flecs 4.0.4 the reference vendors (oracle/_ref/flecs_harness, compiled from the
     reference's flecs sources in place; the per-row arithmetic is the oracle's restatement: Zig cannot be built here).
-    Transform systems only (the reference has no cull), every LocalTransform dirty in frame 0, on a bounded sample."""
+    Transform systems only (the reference has no cull), every LocalTransform dirty in frame 0, on a bounded sample.
+    The binary is a build artefact of the container that holds the reference: where it did not travel, the record
+    says so instead of silently vanishing."""
     import struct
     import subprocess
     import tempfile
 
     from oracle import pyoracle as oracle
 
-    here = os.path.dirname(os.path.abspath(__file__))
-    exe = os.path.join(here, "oracle", "_ref", "flecs_harness")
+    exe = os.path.join(ROOT, "oracle", "_ref", "flecs_harness")
     if not os.path.exists(exe):
-        return None
+        return {"value": None, "kind": "reference-flecs", "sample": "oracle/_ref/flecs_harness is not on this box (it is built "
+                "from /root/reference/vendor/flecs by `make -C oracle ref` where the reference exists)"}
     n_s = 200_000
     lo = oracle.synth_level_offsets(n_s, lo_levels)
     par = oracle.synth_parents(lo)
@@ -174,11 +187,11 @@ def cpu_baseline_flecs(wl, lo_levels):
         try:
             r = subprocess.run([exe, scene, os.path.join(d, "out.bin")], env=dict(os.environ, YFH_TIMES="1"),
                                capture_output=True, text=True, timeout=300)
-        except Exception:  # noqa: BLE001
-            return None
+        except Exception as ex:  # noqa: BLE001
+            return {"value": None, "kind": "reference-flecs", "sample": f"flecs_harness failed: {ex}"}
     ms = [float(line.split(": ")[1].split(" ms")[0]) for line in r.stderr.splitlines() if line.startswith("frame ")]
     if len(ms) < 2:
-        return None
+        return {"value": None, "kind": "reference-flecs", "sample": f"flecs_harness printed no frame times (rc {r.returncode})"}
     med = float(np.median(ms[1:]))
     return {"value": round(n_s / med / 1e3, 3), "unit": "Mentities/s", "cores": 1, "kind": "port",
             "ns_per_entity": round(med * 1e6 / n_s, 2),
@@ -186,30 +199,15 @@ def cpu_baseline_flecs(wl, lo_levels):
                       f"flecs 4.0.4 (TransformSyncSystem rule + both PostTransform sweeps, no cull; median)"}
 
 
-def kernel_symbol(levels_in_group, bounds, has_base, n_entities=1 << 40, n_levels=8):
-    """Name rocprofv3 reports for the launch of a level group (yume_hip.hip launch_trs / launch_chain / launch_first_x)."""
-    hb = "true" if has_base else "false"
-    if not has_base and n_entities <= 64 * 1024 * 64:  # up to 1024 expand tiles: the first launch carries the previous frame's expansion
-        if levels_in_group == 1:
-            return f"void k_frame_trs_x<{bounds}>(FrameArgs, ExpandArgs)"
-        g = next(x for x in (2, 3, 4, 6, 8) if levels_in_group <= x)
-        return f"void k_frame_chain_x<{g}, {bounds}>(FrameArgs, ExpandArgs)"
-    # scenes that outgrow the Infinity Cache use the variants with streaming input loads (YH_BIG_FLAT / YH_BIG_TREE)
-    big = n_entities >= ((5 << 20) if n_levels == 1 else (7 << 19))
-    if levels_in_group == 1:
-        return f"void k_frame_trs{'_big' if big else ''}<{bounds}, {hb}>(FrameArgs)"
-    g = next(x for x in (2, 3, 4, 6, 8) if levels_in_group <= x)
-    return f"void k_frame_chain{'_big' if big and g <= 3 else ''}<{g}, {bounds}, {hb}>(FrameArgs)"
-
-
 def profiled_traffic(workload, symbol):
-    """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC passes (profiles/r*/, newest round first):
-    2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 FETCH_SIZE correction as calibrated in profiles/r01/SUMMARY.md."""
+    """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC passes of this bench command (profiles/r*/,
+    newest round first): 2 x FETCH_SIZE + WRITE_SIZE, KiB units, gfx950 FETCH_SIZE correction as calibrated in
+    profiles/r01/SUMMARY.md.  PMC passes are separate rocprofv3 runs (tools/profile.sh): the number cannot be taken
+    inside a timing run."""
     import csv
     import glob
 
-    here = os.path.dirname(os.path.abspath(__file__))
-    for d in sorted(glob.glob(os.path.join(here, "profiles", "r*")), reverse=True):
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*")), reverse=True):
         vals = {}
         for kind in ("fetch", "write"):
             f = os.path.join(d, f"{workload}_pmc_{kind}_mean_kib_per_dispatch.csv")
@@ -218,37 +216,56 @@ def profiled_traffic(workload, symbol):
                     if r["kernel"] == symbol:
                         vals[kind] = float(r["mean_KiB_per_dispatch"])
         if len(vals) == 2:
-            return (2 * vals["fetch"] + vals["write"]) * 1024.0, os.path.relpath(d, here)
+            return (2 * vals["fetch"] + vals["write"]) * 1024.0, os.path.relpath(d, ROOT)
     return None, None
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world_size != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_size}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        if world_size == 1 and args.gpus > 1:
-            sys.exit(2)
+class Job:
+    """What every workload of this process shares: the context, the ranks, the transport."""
 
-    import torch
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.torch = None
+        self.ctx = None
+        self.info = None
+        self.use_lib_comm = True
+        self.comm_up = False
+        self.comm_err = ""
 
+    def barrier(self):
+        self.ctx.wait()
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_ok(self, ok):
+        if self.dist is None:
+            return bool(ok)
+        flag = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device="cuda")
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+
+def run_workload(job, name, steps, warmup, headline, entities=0):
+    """One configuration: build the scene in HBM, find its dominant launch, time `steps` frames (or, steps = 0, as
+    many as SUB_MIN_TIMED_S needs).  Returns the record; for the headline also what the CPU leg needs."""
     from yume_amd import Context, Scene, _lib, synth
 
-    dist = None
-    if world_size > 1:
-        import torch.distributed as dist
-
-        # one GPU per rank; a launcher that narrows each rank's visible devices to one leaves only index 0
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    wl = WORKLOADS[args.workload]
-    n = args.entities or wl["n"]
+    args, rank, world_size = job.args, job.rank, job.world_size
+    wl = WORKLOADS[name]
+    n = entities or wl["n"]
     if wl["scaling"] == "strong":
         n = n // world_size
     total = n * world_size
@@ -257,8 +274,7 @@ def main():
         planes = np.concatenate([planes, synth.cascade_planes()])
     F = planes.shape[0]
 
-    ctx = Context(local_rank)
-    info = ctx.device_info()
+    ctx = job.ctx
     lo = synth.level_offsets(n, wl["levels"])
     parent = synth.parents(lo, index_base=rank * n)
     scene = Scene(ctx, n, n_levels=wl["levels"], n_frusta=F, bounds_kind=wl["bounds"],
@@ -269,186 +285,274 @@ def main():
     flags = _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC
 
     collective = "none"
-    use_lib_comm = True
     gather = world_size > 1 or args.force_comm
     if world_size == 1 and args.force_comm:
-        ctx.comm_init(1, 0, Context.comm_unique_id())
+        if not job.comm_up:
+            ctx.comm_init(1, 0, Context.comm_unique_id())
+            job.comm_up = True
         collective = "rccl (library, collective stream), one-rank rehearsal"
     if world_size > 1:
-        # product path: the library's own RCCL communicator (ncclAllGather of counts + grouped ncclBroadcast of the
-        # exact-size lists on the library's stream).  If it cannot be brought up on every rank, stand by with
+        # product path: the library's own RCCL communicator.  If it cannot be brought up on every rank, stand by with
         # torch.distributed ("nccl" = RCCL as well) over downloaded lists and say so in the report.
+        dist, torch = job.dist, job.torch
         err = ""
         try:
-            ids = [Context.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            ctx.comm_init(world_size, rank, ids[0])
-            scene.frame(planes, _lib.YH_FRAME_ALL_DIRTY)
-            scene.allgather_draw_lists()        # exact-size exchange (host sync): checks the communicator end to end
-            scene.allgather_draw_lists_async()  # the pipelined exchange the timed frames use
-            scene.gathered_counts(F)
+            if not job.comm_up and job.use_lib_comm:
+                ids = [Context.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                ctx.comm_init(world_size, rank, ids[0])
+                job.comm_up = True
+            if job.use_lib_comm:
+                scene.frame(planes, _lib.YH_FRAME_ALL_DIRTY)
+                scene.allgather_draw_lists()        # exact-size exchange (host sync): checks the communicator end to end
+                scene.allgather_draw_lists_async()  # the pipelined exchange the timed frames use
+                scene.gathered_counts(F)
             ok = 1
         except Exception as ex:  # noqa: BLE001
             ok, err = 0, str(ex)
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        use_lib_comm = bool(flag.item())
-        collective = ("rccl (library, collective stream): one ncclAllGather of the frame's visibility words (n/8 bytes per "
-                      "frustum and rank), every rank expands all ranks' words into the gathered lists; runs beside the next "
-                      "frames" if use_lib_comm
-                      else f"torch.distributed nccl stand-by (library communicator failed: {err[:120]})")
+        if job.use_lib_comm and not job.all_ok(ok):
+            job.use_lib_comm = False
+            job.comm_err = err
+        collective = ("rccl (library, collective stream): one ncclAllGather of the frame's VISIBILITY WORDS (n/8 bytes per "
+                      "frustum and rank, not index lists: 20-32x fewer bytes over xGMI), every rank expands all ranks' words "
+                      "into the gathered draw lists itself; runs beside the next frames" if job.use_lib_comm
+                      else f"torch.distributed nccl stand-by (library communicator failed: {job.comm_err[:120]})")
 
     def step():
         scene.frame(planes, flags)
         if gather:
-            if use_lib_comm:
+            if job.use_lib_comm:
                 scene.allgather_draw_lists_async()
             else:
                 from yume_amd import shard
 
                 shard.allgather_draw_lists_torch([scene.draw_list(f) for f in range(F)], device="cuda")
 
-    def barrier():
-        ctx.wait()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+    def timed(k):
+        job.barrier()
+        t0 = time.perf_counter()
+        for i in range(k):
+            step()
+            if (i + 1) % FRAMES_IN_FLIGHT == 0:
+                ctx.wait()
+        job.barrier()
+        return job.max_over_ranks(time.perf_counter() - t0)
 
-    # Python's cyclic collector is kept out of the timed loops: with torch imported a full collection takes ~40 ms
-    # (seen as one 41 ms gap around the 1300th enqueued frame), as long as a thousand frames.
-    import gc
-
-    gc.collect()
-    gc.disable()
-    # calibration (untimed): HIP events around every launch to find the dominant kernel of a frame
+    # calibration (untimed): HIP events around every launch to find the dominant launch of a frame
     groups = scene.groups()
     dominant = 0
+    ms_all = np.zeros(64)
     if not args.no_kernel_events:
         scene.set_kernel_timing(1)
-        for _ in range(20):
+        for _ in range(8 if n > 64_000_000 else 20):
             step()
         ms_all, _ = scene.group_timings()
         ms_all = ms_all.astype(np.float64)
         dominant = int(np.argmax(ms_all[: len(groups)]))
         scene.set_kernel_timing(0)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    barrier()
-    # timed region: K frames; on every (K / 25)-th frame, between every 4th and every 64th (25 samples at the default
-    # K = 1600: an instrumented frame costs the stream ~20 us, 1-2 % of `value` at that rate), the
-    # transform launches carry a pair of HIP events each (hipExtLaunchKernelGGL on the library's stream: the dispatch's
-    # own start/end timestamps, the ones rocprofv3's kernel trace reports; nothing is added to the stream).  All transform launches of a sampled
-    # frame, not just the dominant one: a launch whose predecessor is not instrumented reads ~3 us long.
-    period = max(4, min(64, args.steps // 25))
+    if steps <= 0:  # sub-record: as many frames as SUB_MIN_TIMED_S of GPU work needs (the same count on every rank)
+        probe = timed(10) / 10
+        steps = int(min(20000, max(20, math.ceil(SUB_MIN_TIMED_S / max(probe, 1e-7)))))
+    # timed region: K frames.  On every period-th frame the transform launches carry a pair of HIP events each
+    # (hipExtLaunchKernelGGL on the library's stream: the dispatch's own start/end timestamps, the ones rocprofv3's
+    # kernel trace reports; nothing is added to the stream) — all transform launches of a sampled frame, not just the
+    # dominant one: a launch whose predecessor is not instrumented reads ~3 us long.  An instrumented frame costs the
+    # stream ~20 us: 25 samples at most for short frames, every 4th frame for frames of milliseconds.
+    period = max(4, min(64, steps // 25))
     if not args.no_kernel_events:
         scene.set_kernel_timing(-1, period)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step()
-        if (i + 1) % FRAMES_IN_FLIGHT == 0:
-            ctx.wait()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(steps)
 
-    # dominant kernel: mean launch duration from the HIP events recorded inside the timed region
-    roofline = None
     counts, bcounts = scene.counts()
-    vis_sum = float(counts[:F].sum()) / n
+    names = scene.group_kernel_names()
+    list_entries = float(counts[:F].sum())
+    own_frame, lists_frame = algorithmic_bytes(wl, lo, parent, 0, n, F, list_entries)
+    ms_frame = elapsed / steps * 1e3
+    working_set = own_frame + lists_frame
+    cache_assisted = working_set < INFINITY_CACHE_BYTES
+    roofline = None
     if not args.no_kernel_events:
         ms, samples = scene.group_timings()
         ms = ms.astype(np.float64)
         g = dominant
         first, end = int(groups[g][2]), int(groups[g][3])
-        b = algorithmic_bytes(wl, lo, parent, first, end, vis_sum)
-        achieved = b / (ms[g] * 1e-3) / 1e9
-        sym = kernel_symbol(int(groups[g][1]) - int(groups[g][0]) + 1, wl["bounds"], int(groups[g][0]) > 0, n, wl["levels"])
-        traffic, traffic_src = profiled_traffic(args.workload, sym) if n == wl["n"] // (world_size if wl["scaling"] == "strong" else 1) else (None, None)
+        own, _ = algorithmic_bytes(wl, lo, parent, first, end, F, 0.0)
+        achieved = own / (ms[g] * 1e-3) / 1e9 if ms[g] > 0 else 0.0
+        sym = names[g] if g < len(names) else ""
+        traffic, traffic_src = (profiled_traffic(name, sym) if n == wl["n"] // (world_size if wl["scaling"] == "strong" else 1)
+                                else (None, None))
         # the PMC passes average per kernel NAME: if another launch of the frame runs the same kernel (cfg4: levels 2..4
         # and 5..7 are both k_frame_chain_big<3>), that average is not this launch's traffic
-        same = [q for q in groups if kernel_symbol(int(q[1]) - int(q[0]) + 1, wl["bounds"], int(q[0]) > 0, n, wl["levels"]) == sym]
+        same = [q for q in names if q == sym]
         if len(same) > 1 and traffic is not None:
             traffic, traffic_src = None, f"{traffic_src}: per-name mean {traffic:.0f} B covers {len(same)} launches of the frame"
+        frac = achieved / HBM_PEAK_GBPS
+        # what bounds the launch: a streaming kernel is HBM-bound when it runs near the measured copy ceiling
+        # (0.78 of the 8 TB/s figure); the 5-frusta cull of cfg3 is bound by vector-ALU issue instead
+        bound = "hbm"
+        note = None
+        if cache_assisted:
+            note = (f"cache-assisted: the frame's {working_set / 1e6:.0f} MB working set stays in the 256 MB Infinity Cache from "
+                    "one frame to the next, so `achieved` is not an HBM rate")
         roofline = {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "bound": bound, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(frac, 4), "traffic": traffic, "traffic_source": traffic_src,
             "kernel_symbol": sym,
             "kernel": f"{sym.split('<')[0].replace('void ', '')} levels {int(groups[g][0])}..{int(groups[g][1])}",
-            "kernel_entities": end - first, "kernel_ms": round(float(ms[g]), 5), "kernel_samples": int(samples[g]), "kernel_sampling_period": period,
-            "algorithmic_bytes_per_launch": b, "algorithmic_bytes_per_entity": round(b / (end - first), 2),
+            "kernel_entities": end - first, "kernel_ms": round(float(ms[g]), 5), "kernel_samples": int(samples[g]),
+            "kernel_sampling_period": period,
+            "algorithmic_bytes_per_launch": own, "algorithmic_bytes_per_entity": round(own / (end - first), 2),
+            "bytes_charged": "TRS + parent index + bounds + 64 B per distinct parent in, world matrices + visibility words and "
+                             "count bytes out; the 4 B per emitted draw index are k_expand's and are charged to the frame only",
             "launch_ms_all_calibration": [round(float(x), 5) for x in ms_all[: len(groups)]],
             "expand_stage_ms_calibration": round(float(ms_all[63]), 5),
             "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
+            "frame_frac": round((own_frame + lists_frame) / (ms_frame * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
         }
+        if note:
+            roofline["note"] = note
     scene.set_kernel_timing(False)
 
-    # un-instrumented pass of the same K steps (reported beside, never as `value`)
-    barrier()
-    t1 = time.perf_counter()
-    for i in range(args.steps):
-        step()
-        if (i + 1) % FRAMES_IN_FLIGHT == 0:
-            ctx.wait()
-    barrier()
-    elapsed_plain = time.perf_counter() - t1
-    if dist is not None:
-        t = torch.tensor([elapsed_plain], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_plain = float(t.item())
+    rec = {
+        "value": round(total * steps / elapsed / 1e6, 2),
+        "unit": "Mentities/s",
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(ms_frame, 5),
+        "timed_region_ms": round(elapsed * 1e3, 3),
+        "scaling": wl["scaling"],
+        "config": {"workload": f"{name}: {wl['desc']}", "entities_per_gpu": n, "entities_total": total,
+                   "levels": wl["levels"], "frusta": F, "launches_per_frame": int(len(groups)),
+                   "level_groups": [[int(x) for x in q] for q in groups], "kernels": names, "collective": collective},
+        "roofline": roofline,
+        "frame_hbm_frac": round((own_frame + lists_frame) / (ms_frame * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "frame_algorithmic_bytes_per_entity": round((own_frame + lists_frame) / n, 2),
+        "visible_fraction": [round(float(c) / n, 4) for c in counts[:F]],
+        "boundary_cases": [int(x) for x in bcounts[:F]],
+    }
+    extra = None
+    if headline:
+        # un-instrumented pass of the same K steps (reported beside, never as `value`)
+        elapsed_plain = timed(steps)
+        rec["value_without_kernel_events"] = round(total * steps / elapsed_plain / 1e6, 2)
+        # per-frame latency with a host sync every frame (what an engine that reads counts each frame sees)
+        lat = []
+        for _ in range(min(20, steps)):
+            a = time.perf_counter()
+            scene.frame(planes, _lib.YH_FRAME_ALL_DIRTY)
+            if gather and job.use_lib_comm:
+                scene.allgather_draw_lists()
+            lat.append(time.perf_counter() - a)
+        rec["frame_latency_ms_synced_median"] = round(float(np.median(lat)) * 1e3, 5)
+        extra = (wl, n, lo, parent, planes)
+    scene.close()
+    return rec, extra
 
-    # per-frame latency with a host sync every frame (what an engine that reads counts each frame sees)
-    lat = []
-    for _ in range(min(50, args.steps)):
-        a = time.perf_counter()
-        scene.frame(planes, _lib.YH_FRAME_ALL_DIRTY)
-        if gather and use_lib_comm:
-            scene.allgather_draw_lists()
-        lat.append(time.perf_counter() - a)
 
-    gc.enable()
-    b_frame = algorithmic_bytes(wl, lo, parent, 0, n, vis_sum)
+def main():
+    args = parse()
+    job = Job(args)
+    rank, world_size = job.rank, job.world_size
+    if world_size != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_size}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        if world_size == 1 and args.gpus > 1:
+            sys.exit(2)
+
+    import torch
+
+    from yume_amd import Context
+
+    job.torch = torch
+    if world_size > 1:
+        import torch.distributed as dist
+
+        # one GPU per rank; a launcher that narrows each rank's visible devices to one leaves only index 0
+        job.local_rank = job.local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(job.local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", job.local_rank))
+        job.dist = dist
+    job.ctx = Context(job.local_rank)
+    job.info = job.ctx.device_info()
+
+    # Python's cyclic collector is kept out of the timed loops: with torch imported a full collection takes ~40 ms
+    # (seen as one 41 ms gap around the 1300th enqueued frame), as long as a thousand cfg2 frames.
+    import gc
+
+    gc.collect()
+    gc.disable()
+
+    head, extra = run_workload(job, args.workload, args.steps, args.warmup, True, args.entities)
     result = {
         "metric": "Mentities/s transformed+culled per frame",
-        "value": round(total * args.steps / elapsed / 1e6, 2),
+        "value": head["value"],
         "unit": "Mentities/s",
         "n_gpus": world_size,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "ms_per_step": head["ms_per_step"],
         "higher_is_better": True,
-        "scaling": wl["scaling"],
+        "scaling": head["scaling"],
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {wl['desc']}", "entities_per_gpu": n, "entities_total": total,
-                   "levels": wl["levels"], "frusta": F, "launches_per_frame": int(len(groups)),
-                   "level_groups": [[int(x) for x in q] for q in groups], "collective": collective,
-                   "device": info["name"], "arch": info["arch"]},
-        "roofline": roofline,
-        "frame_hbm_frac": round(b_frame * world_size / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBPS * world_size), 4),
-        "frame_algorithmic_bytes_per_entity": round(b_frame / n, 2),
-        "value_without_kernel_events": round(total * args.steps / elapsed_plain / 1e6, 2),
-        "frame_latency_ms_synced_median": round(float(np.median(lat)) * 1e3, 5),
-        "visible_fraction": [round(float(c) / n, 4) for c in counts[:F]],
-        "boundary_cases": [int(x) for x in bcounts[:F]],
+        "config": dict(head["config"], device=job.info["name"], arch=job.info["arch"]),
+        "roofline": head["roofline"],
     }
+    for k in ("timed_region_ms", "frame_hbm_frac", "frame_algorithmic_bytes_per_entity", "value_without_kernel_events",
+              "frame_latency_ms_synced_median", "visible_fraction", "boundary_cases"):
+        result[k] = head[k]
+
+    def emit():
+        if rank == 0:
+            print(json.dumps(result, default=float), flush=True)
+
+    # sub-records: the other configurations, each >= SUB_MIN_TIMED_S of timed frames.  A watchdog makes sure the
+    # headline line is printed even if one of them hangs (every rank exits at the same deadline).
+    subs = [] if args.no_sub else [w for w in (args.sub.split(",") if args.sub else SUB_ORDER) if w in WORKLOADS and w != args.workload]
+    result["workloads"] = {}
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(WATCHDOG_S):
+            result["workloads"]["_error"] = f"sub-records did not finish within {WATCHDOG_S:.0f} s; the line was printed by the watchdog"
+            emit()
+            os._exit(0)
+
+    if subs:
+        threading.Thread(target=watchdog, daemon=True).start()
+    t_sub = time.perf_counter()
+    for w in subs:
+        late = job.max_over_ranks(time.perf_counter() - t_sub) > SUB_BUDGET_S
+        if late:
+            result["workloads"][w] = {"skipped": f"sub-record budget of {SUB_BUDGET_S:.0f} s used up"}
+            continue
+        try:
+            rec, _ = run_workload(job, w, 0, 20 if WORKLOADS[w]["n"] <= 2_000_000 else 5, False)
+            ok, err = True, ""
+        except Exception as ex:  # noqa: BLE001
+            rec, ok, err = None, False, str(ex)
+        result["workloads"][w] = rec if ok else {"error": err[:300]}
+        if not job.all_ok(ok):  # a rank failed: the others would wait for it in the next workload's collectives
+            break
+    done.set()
+
+    gc.enable()
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
-        result.update(cpu_baseline(args, wl, n, lo, parent, planes, args.cpu_seconds))
-        result["cpu_baseline_in_flecs"] = cpu_baseline_flecs(wl, wl["levels"])
+        wl, n, lo, parent, planes = extra
+        result.update(cpu_baseline(wl, n, lo, parent, planes, args.cpu_seconds))
+        result["cpu_baseline_in_flecs"] = cpu_baseline_flecs(8)
     elif rank == 0:
         result["cpu_baseline"] = None
 
-    scene.close()
-    ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(result, default=float), flush=True)
+    job.ctx.close()
+    if job.dist is not None:
+        job.dist.barrier()
+        job.dist.destroy_process_group()
+    emit()
 
 
 if __name__ == "__main__":

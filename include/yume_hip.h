@@ -139,7 +139,14 @@ int yh_upload_world_aos68(yh_scene* s, const void* column, uint64_t first, uint6
 /* The onSet hooks (transform.zig:46-51, 92-97): mark a range dirty without re-uploading matrices.       */
 int yh_mark_dirty(yh_scene* s, int local, int world, uint64_t first, uint64_t count);
 
-/* Bounds (meshes.zig:72-95). */
+/* Ordering of uploads: every yh_upload_ call is ordered behind the frames already enqueued on this context
+ * (YH_FRAME_ASYNC) — it copies on the context's stream, or waits for that stream first — and returns when its copy
+ * is done: a frame never sees a half-written input and an upload never overtakes an earlier frame.  yh_set_root /
+ * yh_upload_root_aos68 only change what the NEXT frame is handed by value.
+ *
+ * Bounds (meshes.zig:72-95).  Mesh-table scenes: every entity refers to mesh 0 until yh_upload_mesh_ids says
+ * otherwise; the table may be re-uploaded with more or fewer meshes, but never fewer than the largest id in use
+ * (YH_ERR_STATE) — upload the ids of the whole scene again first.                                          */
 int yh_upload_aabb(yh_scene* s, const float* const min_planes[3], const float* const max_planes[3],
                    uint64_t first, uint64_t count);
 int yh_upload_mesh_aabbs(yh_scene* s, const float* table /* n_meshes x 6: min.xyz,max.xyz */, uint32_t n_meshes);
@@ -244,6 +251,9 @@ int yh_scene_set_kernel_timing(yh_scene* s, int enable);
 int yh_scene_set_kernel_timing_period(yh_scene* s, uint32_t period);
 int yh_scene_get_groups(yh_scene* s, uint32_t* quads, uint32_t cap, uint32_t* n_groups);
 int yh_scene_get_group_timings(yh_scene* s, float* mean_ms, uint32_t* samples, uint32_t cap);
+/* The kernel each group's launch of the LAST frame ran, spelled as rocprofv3's kernel trace spells it (one per
+ * line, group order): the harness looks a launch's counters up by the name the library really dispatched.   */
+int yh_scene_get_group_kernel_names(yh_scene* s, char* buf, uint64_t cap, uint32_t* n_groups);
 /* Hierarchy launches (TRS scenes): levels are cut into groups of consecutive levels, one kernel launch per
  * group; inside a group an entity re-derives its ancestors' matrices (a walk up the parent chain) instead of
  * waiting for a launch boundary.  Results do not depend on the plan.  yh_scene_set_grouping: exactly

@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest` on a box without an AMD GPU driver (no /dev/kfd: the CPU build container) skips the gpu-marked
+    tests instead of erroring in the session fixture.  Where the driver IS present nothing is skipped: a GPU box whose
+    library or device is broken must fail loudly."""
+    if os.path.exists("/dev/kfd"):
+        return
+    skip = pytest.mark.skip(reason="no AMD GPU driver on this box (/dev/kfd missing): gpu tests run on the MI355X box")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure): scalar C restatement of the reference's path."""

@@ -138,20 +138,24 @@ def test_product_does_not_import_the_oracle():
                 assert "pyoracle" not in txt and "yume_oracle" not in txt and "import oracle" not in txt, f
 
 
-def test_bench_kernel_names_exist_in_the_library():
-    """bench.py looks up the dominant launch's PMC traffic by the name rocprofv3 reports for it; every name it can
-    produce for the benchmark workloads must be a kernel the library really contains."""
+def test_bench_parses_and_names_the_largest_single_gpu_configuration_by_default():
+    """The driver-timed line must be the largest single-GPU configuration (cfg5, 256M instances: far outside the
+    Infinity Cache), with the other GPU configurations as sub-records."""
     import importlib.util
+    import sys
 
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    out = subprocess.run(["nm", "-C", os.path.join(ROOT, "yume_amd", "libyume_hip.so")], capture_output=True, text=True, check=True).stdout
-    have = {parts[2] for parts in (line.split(None, 2) for line in out.splitlines()) if len(parts) == 3}
-    for n, levels, bounds in ((1_000_000, 8, 1), (16_000_000, 1, 1), (12_500_000, 8, 1), (256_000_000, 1, 2), (10_000, 1, 1)):
-        for g in (1, 2, 3, 5, 8):
-            for has_base in (False, True):
-                if levels == 1 and (g > 1 or has_base):
-                    continue
-                sym = bench.kernel_symbol(g, bounds, has_base, n, levels)
-                assert sym in have, sym
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        args = bench.parse()
+    finally:
+        sys.argv = argv
+    assert args.workload == "cfg5" and args.gpus == 1 and not args.no_sub
+    assert bench.WORKLOADS["cfg5"]["n"] == max(w["n"] for w in bench.WORKLOADS.values())
+    assert [w for w in bench.SUB_ORDER if w != args.workload] == ["cfg2", "cfg3", "cfg4"]
+    # the transform launch is charged its own bytes only: the 4 B per emitted index belong to the expansion
+    lo = np.array([0, 1000], np.uint32)
+    own, lists = bench.algorithmic_bytes(bench.WORKLOADS["cfg3"], lo, None, 0, 1000, 5, 1234.0)
+    assert own == 1000 * (40 + 64 + 24) + 5 * (1000 / 8 + 1000 / 64) and lists == 4 * 1234.0

@@ -340,3 +340,71 @@ def test_batched_decompose_equals_the_oracle_bit_for_bit(ctx, oracle):
         with pytest.raises(_lib.YumeHipError) as e:
             s.decompose("local")
         assert e.value.code == _lib.YH_ERR_STATE
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_chain_replay_equals_one_level_per_launch_on_tiny_mixed_levels(ctx, oracle, seed):
+    """k_chain_mat4 replays its ancestors' rule in registers while other lanes OF THE SAME LAUNCH rewrite those
+    ancestors' rows (wdirty 0 -> 1, world in the forward branch, lmat in the reverse branch).  The invariant beside the
+    kernel says the replay never reads what a lane rewrites.  Forced shape: 8 levels of 2..60 entities (the whole tree
+    is a few waves of one launch), every mix of local-dirty / world-dirty / clean rows and a clean or dirty root —
+    the grouped plan must leave exactly what one launch per level (set_grouping(1): parents finished before children
+    start) and the oracle leave, rows, flags and lists."""
+    from yume_amd import Scene, _lib
+
+    rng = np.random.default_rng(900 + seed)
+    sizes = [int(rng.integers(2, 60)) for _ in range(8)]
+    lo = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    n = int(lo[-1])
+    par = oracle.synth_parents(lo, seed=seed)
+    bounds = oracle.synth_aabb(n, seed=seed)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    local0 = oracle.compose_batch(oracle.synth_trs(n, int(lo[1]), seed=seed))
+    world0 = np.zeros(n, oracle.T68)
+    world0["m"][:, [0, 5, 10, 15]] = 1
+
+    def script(s, local, world, root, plan_one):
+        if plan_one:
+            s.set_grouping(1)
+        out = []
+        r = np.random.default_rng(77 + seed)  # the same edits for both plans
+        for frame in range(6):
+            if frame == 0:
+                local["dirty"] = 1
+                world["dirty"] = 1
+            else:
+                ld = r.random(n) < 0.25
+                wd = (r.random(n) < 0.25) & ~ld
+                for e in np.flatnonzero(ld):
+                    local["m"][e] = 0 if r.random() < 0.05 else oracle.compose(r.uniform(-5, 5, 3), r.uniform(-1, 1, 4), r.uniform(0.5, 2, 3))
+                for e in np.flatnonzero(wd):
+                    world["m"][e] = oracle.compose(r.uniform(-50, 50, 3), r.uniform(-1, 1, 4), r.uniform(0.5, 2, 3))
+                local["dirty"][ld] = 1
+                world["dirty"][wd] = 1
+                if frame % 2 == 0:
+                    root["m"][0] = oracle.compose(r.uniform(-3, 3, 3), r.uniform(-1, 1, 4), [1, 1, 1])
+                    root["dirty"] = 1
+                    s.set_root(root["m"][0])
+            s.upload_local_aos68(local)
+            s.upload_world_aos68(world)
+            oracle.frame_aos68(world, local, par, lo, root)
+            s.frame(planes, flags=0)
+            out.append((s.world_aos68(), s.local_aos68(), s.draw_list(0).copy(), world.copy(), local.copy()))
+        return out
+
+    runs = []
+    for plan_one in (False, True):
+        with Scene(ctx, n, n_levels=8, n_frusta=1, local_kind=_lib.YH_LOCAL_MAT4) as s:
+            s.upload_hierarchy(par, lo)
+            s.upload_aabb(np.ascontiguousarray(bounds[:, 0:3].T), np.ascontiguousarray(bounds[:, 3:6].T))
+            groups = s.groups()
+            if not plan_one:
+                assert len(groups) < 8, "the planner is expected to group these tiny levels into chain launches"
+            runs.append(script(s, local0.copy(), world0.copy(), oracle.identity68(), plan_one))
+    for frame, (a, b) in enumerate(zip(*runs)):
+        with np.errstate(all="ignore"):
+            assert_same_values(a[0]["m"], b[0]["m"], f"frame {frame}: world, chain vs one level per launch")
+            assert_same_values(a[1]["m"], b[1]["m"], f"frame {frame}: local, chain vs one level per launch")
+            assert_same_values(a[0]["m"], a[3]["m"], f"frame {frame}: world vs oracle")
+            assert_same_values(a[1]["m"], a[4]["m"], f"frame {frame}: local vs oracle")
+        assert np.array_equal(a[2], b[2]) and not a[0]["dirty"].any() and not a[1]["dirty"].any()

@@ -322,6 +322,50 @@ def test_mesh_table_bounds(ctx, oracle):
         assert np.array_equal(s.draw_list(0), np.flatnonzero(vis[0]).astype(np.uint32) + np.uint32(base))
 
 
+def test_mesh_ids_default_to_zero_and_the_table_cannot_shrink_below_an_id_in_use(ctx, oracle):
+    """A frame (and the consumers) before yh_upload_mesh_ids covered every entity must index the mesh table in bounds:
+    ids start out as 0.  A later table with fewer meshes than the largest id in use is refused."""
+    from yume_amd import Scene, _lib
+
+    n, nm = 300_001, 200
+    trs = oracle.synth_trs(n, n)
+    table = oracle.synth_mesh_table(nm)
+    ids = oracle.synth_mesh_ids(n, nm)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    exp = oracle.frame_trs(trs, np.full(n, 0xFFFFFFFF, np.uint32), np.array([0, n], np.uint32), n_threads=8)
+    with Scene(ctx, n, n_frusta=1, bounds_kind=2, max_meshes=nm) as s:
+        s.upload_flat()
+        s.upload_trs(trs)
+        s.upload_mesh_aabbs(table)
+        s.upload_vertex_counts(np.arange(nm, dtype=np.uint32) + 3)
+        # no ids at all: every entity is mesh 0
+        s.frame(planes)
+        vis0, _ = oracle.cull(exp, table, planes, mesh_id=np.zeros(n, np.uint32), n_threads=8)
+        assert np.array_equal(s.draw_list(0), np.flatnonzero(vis0[0]).astype(np.uint32))
+        b, bids, _, cmds = s.mesh_buckets(0)
+        assert b[0, 2] == bids.size and not b[1:, 2].any() and (cmds[:, 0] == 3).all()
+        # ids for the first half only: the second half stays mesh 0
+        half = n // 2
+        s.upload_mesh_ids(ids[:half])
+        mixed = np.concatenate([ids[:half], np.zeros(n - half, np.uint32)])
+        s.frame(planes)
+        vis1, _ = oracle.cull(exp, table, planes, mesh_id=mixed, n_threads=8)
+        assert np.array_equal(s.draw_list(0), np.flatnonzero(vis1[0]).astype(np.uint32))
+        # shrinking the table below an id in use is refused; after a full re-upload of small ids it is accepted
+        top = int(ids[:half].max())
+        with pytest.raises(_lib.YumeHipError) as e:
+            s.upload_mesh_aabbs(table[:top])
+        assert e.value.code == _lib.YH_ERR_STATE
+        s.upload_mesh_aabbs(table[: top + 1])
+        s.upload_mesh_ids(ids % 7)
+        s.upload_mesh_aabbs(table[:7])
+        s.frame(planes)
+        vis2, _ = oracle.cull(exp, table[:7], planes, mesh_id=ids % 7, n_threads=8)
+        assert np.array_equal(s.draw_list(0), np.flatnonzero(vis2[0]).astype(np.uint32))
+        b, bids, _, _ = s.mesh_buckets(0)
+        assert b.shape[0] == 7 and b[:, 2].sum() == bids.size
+
+
 def test_draw_list_consumer_object_data_and_draw_records(ctx, oracle):
     """GPUObjectData{model_matrix} and vkCmdDraw arguments for the visible entities, in list order —
     the reference fills them on the CPU (GAL/vulkan/RenderApi.zig:1397-1404, 1441)."""
@@ -557,3 +601,42 @@ def test_draw_list_overflow_reports_required_size(ctx, oracle):
         written = C.c_uint64()
         rc = _lib.lib().yh_get_draw_list(s._h, 0, out.ctypes.data_as(C.c_void_p), 10, C.byref(written))
         assert rc == _lib.YH_ERR_CAPACITY and written.value == exp
+
+
+def test_reported_kernel_names_are_kernels_of_the_library(ctx, oracle):
+    """bench.py looks a launch's PMC traffic up by the name the library reports for it
+    (yh_scene_get_group_kernel_names): every name must be a kernel the library really contains, spelled as the
+    symbol table (and rocprofv3's kernel trace) spells it."""
+    import subprocess
+
+    from yume_amd import Scene, _lib
+
+    so = _lib.LIB_PATH
+    nm = "nm" if subprocess.run(["which", "nm"], capture_output=True).returncode == 0 else "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-C", so], capture_output=True, text=True, check=True).stdout
+    have = {parts[2] for parts in (line.split(None, 2) for line in out.splitlines()) if len(parts) == 3}
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    seen = set()
+    cases = [(300_000, 8, 1, 0, 0), (300_000, 8, 1, 0, 1), (5_000_000, 8, 1, 0, 0), (6_000_000, 1, 1, 0, 0), (200_000, 1, 2, 0, 0),
+             (50_000, 3, 0, 0, 0), (80_000, 6, 1, 1, 0), (80_000, 1, 2, 1, 0), (4_000_000, 2, 1, 1, 0)]
+    for n, levels, bounds, mat4, one_per_level in cases:
+        lo = oracle.synth_level_offsets(n, levels)
+        with Scene(ctx, n, n_levels=levels, n_frusta=1 if bounds else 0, bounds_kind=bounds, max_meshes=4 if bounds == 2 else 0,
+                   local_kind=_lib.YH_LOCAL_MAT4 if mat4 else _lib.YH_LOCAL_TRS) as s:
+            s.upload_hierarchy(oracle.synth_parents(lo), lo)
+            if not mat4:
+                s.fill_synthetic()
+            elif bounds == 2:
+                s.upload_mesh_aabbs(oracle.synth_mesh_table(4))
+            if one_per_level:
+                s.set_grouping(1)
+            for flags in ((0,) if mat4 else (_lib.YH_FRAME_ALL_DIRTY, _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC, _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC)):
+                s.frame(planes if bounds else None, flags)
+                names = s.group_kernel_names()
+                assert len(names) == len(s.groups())
+                for k in names:
+                    assert k in have, k
+                    seen.add(k.split("<")[0])
+            ctx.wait()
+    assert {"void k_frame_trs", "void k_frame_trs_big", "void k_frame_chain", "void k_frame_chain_big", "void k_frame_chain_x",
+            "void k_frame_trs_x", "void k_level_mat4", "void k_chain_mat4"} <= seen, seen

@@ -127,6 +127,7 @@ SIGNATURES = {
     "yh_scene_set_plan": (_int, [_vp, _u32, _vp]),
     "yh_scene_get_groups": (_int, [_vp, _vp, _u32, C.POINTER(_u32)]),
     "yh_scene_get_group_timings": (_int, [_vp, _vp, _vp, _u32]),
+    "yh_scene_get_group_kernel_names": (_int, [_vp, _vp, _u64, C.POINTER(_u32)]),
     "yh_scene_set_grouping": (_int, [_vp, _u32]),
     "yh_extract_planes": (None, [_vp, _vp]),
     "yh_mat4_mul": (None, [_vp, _vp, _vp]),

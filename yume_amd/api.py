@@ -339,6 +339,13 @@ class Scene:
         self._ck(L.lib().yh_scene_get_groups(self._h, _ptr(q), L.YH_MAX_LEVELS, C.byref(n)))
         return q[: n.value].copy()
 
+    def group_kernel_names(self):
+        """Kernel (rocprofv3 spelling) each level group's launch of the last frame ran."""
+        buf = C.create_string_buffer(64 * 200)
+        n = C.c_uint32()
+        self._ck(L.lib().yh_scene_get_group_kernel_names(self._h, buf, len(buf), C.byref(n)))
+        return buf.value.decode().split("\n")[: n.value]
+
     def group_timings(self):
         ms = np.zeros(L.YH_MAX_LEVELS, np.float32)
         cnt = np.zeros(L.YH_MAX_LEVELS, np.uint32)

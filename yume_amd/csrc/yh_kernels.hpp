@@ -479,6 +479,13 @@ __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, cons
 // lane in this launch: the only rewrite is wdirty 0 -> 1 on a row the rule found dirty anyway, so the replay's
 // outcome is the same; world[a] is only rewritten in the forward branch, where the replay does not read it; lmat[a]
 // only in the reverse branch, where the replay does not read it either.
+// INVARIANT (a checkable rule for whoever adds a writer to a level launch): inside k_level_mat4 / k_chain_mat4 the only
+// store to wdirty is 0 -> 1 on the lane's OWN row, no launch clears a flag (that is k_clear_dirty / k_sweep_dirty's
+// job, after the last level), a lane stores world[e] only where ld || pd and lmat[e] only where !(ld || pd) && wd of
+// its own row e, and a replay reads world[anc] only where !(ld_anc || pd) and lmat[anc] only where ld_anc || pd: the
+// sets "rows a lane may store" and "rows a replay may load" are disjoint per array.  Pinned by
+// tests/test_gpu_columns.py::test_chain_replay_equals_one_level_per_launch_on_tiny_mixed_levels (8 tiny mixed levels
+// in one launch against one launch per level and the oracle).
 template <int G, int BOUNDS, bool HAS_BASE>
 __global__ __launch_bounds__(YH_BLOCK) void k_chain_mat4(const FrameArgs a, const uint32_t root_dirty) {
     const uint32_t tid = threadIdx.x;
