@@ -322,6 +322,10 @@ int yh_allgather_draw_lists_async(yh_scene* s);
 /* Testing aid (one GPU, no communicator): runs the gather's expansion on fake_ranks copies of this scene's own
  * words, rank r owning ids id_base + r * n_entities; read the result like a real gather's.                      */
 int yh_gather_selftest(yh_scene* s, uint32_t fake_ranks);
+/* The same with n_shards DIFFERENT shards on one GPU: the scenes of one context stand for the ranks (rank order),
+ * each with its own row length and id_base — e.g. one scene per part of yh_partition_subtrees, all framed with the
+ * same frusta.  The gathered lists land in shards[0], as on rank 0 after a real exchange.                    */
+int yh_gather_selftest_shards(yh_scene* const* shards, uint32_t n_shards);
 int yh_get_gathered_counts(yh_scene* s, uint32_t* all_counts /* n_ranks x n_frusta */);
 int yh_get_gathered_draw_list(yh_scene* s, uint32_t frustum, uint32_t* out, uint64_t cap, uint64_t* written);
 

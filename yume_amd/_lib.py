@@ -122,6 +122,7 @@ SIGNATURES = {
     "yh_get_mesh_buckets": (_int, [_vp, _u32, _vp, _u32, _vp, _u64, C.POINTER(_u64)]),
     "yh_allgather_draw_lists_async": (_int, [_vp]),
     "yh_gather_selftest": (_int, [_vp, _u32]),
+    "yh_gather_selftest_shards": (_int, [_vp, _u32]),
     "yh_get_gathered_counts": (_int, [_vp, _vp]),
     "yh_decompose": (_int, [_vp, _int, _vp, _vp, _u64, _u64]),
     "yh_scene_set_plan": (_int, [_vp, _u32, _vp]),

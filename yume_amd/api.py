@@ -367,6 +367,12 @@ class Scene:
         """One-GPU rehearsal of the gather's expansion: fake_ranks copies of this scene's own visibility words."""
         self._ck(L.lib().yh_gather_selftest(self._h, int(fake_ranks)))
 
+    @staticmethod
+    def gather_selftest_shards(shards):
+        """One-GPU rehearsal of the gather with R different shard scenes (rank order); results land in shards[0]."""
+        arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
+        L.check(L.lib().yh_gather_selftest_shards(arr, len(shards)), shards[0].ctx.handle)
+
     def gathered_counts(self, n_frusta, n_ranks=None):
         out = np.zeros((n_ranks or self.ctx.n_ranks, max(1, n_frusta)), np.uint32)
         self._ck(L.lib().yh_get_gathered_counts(self._h, _ptr(out)))

@@ -2094,70 +2094,110 @@ extern "C" int yh_allgather_draw_lists_async(yh_scene* s) {
     return YH_OK;
 }
 
-// Testing aid (one GPU): the gather's expansion fed with `fake_ranks` copies of this scene's own words, rank r
-// pretending to own ids id_base + r * n_entities — what R identical shards would have sent.  Results are read with
+// Testing aid (one GPU, no communicator): the gather's expansion fed with what R ranks would have all-gathered.
+// Row r of the receive buffer is shard r's visibility words of its last frame, zero-padded to the longest shard's
+// row length exactly as send_pad pads them on a real rank (plus `extra_words` more: a longer shard that is not here),
+// peer r = that shard's word count and id base.  The expansion runs on out's buffers; results are read from `out` with
 // yh_get_gathered_counts / yh_get_gathered_draw_list as after a real gather.
-extern "C" int yh_gather_selftest(yh_scene* s, uint32_t fake_ranks) {
-    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_gather_selftest: scene is NULL");
-    yh_ctx* ctx = s->ctx;
-    ARG_TRY(ctx, fake_ranks >= 1 && fake_ranks <= 64, "yh_gather_selftest: 1..64 ranks");
-    if (ctx->comm || s->g_ready) return fail(ctx, YH_ERR_STATE, "yh_gather_selftest: not on a scene or context that gathers for real");
-    if (s->frames == 0 || s->last_n_frusta == 0) return fail(ctx, YH_ERR_STATE, "yh_gather_selftest: no culling frame has run");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (int rc = sync_scene(s)) return rc;
-    const uint32_t R = fake_ranks, F = s->last_n_frusta;
-    // word rows one longer than this scene's, as if another shard were the longest: exercises the zero padding
-    const uint32_t W = s->n_chunks + 3;
-    if (int rc = ensure_all_counts(s, (int)R)) return rc;
-    s->g_ranks = (int)R;
-    s->g_words = W;
-    s->g_tile_words = W <= 32u * 4096u ? 64u : (uint32_t)YH_EXPAND_WORDS_MAX;
-    s->g_tiles = (W + s->g_tile_words - 1) / s->g_tile_words;
+struct FakeRank {
+    const uint64_t* words;
+    uint32_t n_chunks, id_base;
+};
+static int gather_selftest_run(yh_scene* out, const std::vector<FakeRank>& ranks, uint32_t F, uint32_t extra_words) {
+    yh_ctx* ctx = out->ctx;
+    const uint32_t R = (uint32_t)ranks.size();
+    uint32_t W = 0;
+    for (const FakeRank& r : ranks) W = std::max(W, r.n_chunks);
+    W += extra_words;
+    if (int rc = ensure_all_counts(out, (int)R)) return rc;
+    out->g_ranks = (int)R;
+    out->g_words = W;
+    out->g_tile_words = W <= 32u * 4096u ? 64u : (uint32_t)YH_EXPAND_WORDS_MAX;
+    out->g_tiles = (W + out->g_tile_words - 1) / out->g_tile_words;
     uint64_t* gmask = nullptr;
     uint32_t *gtile = nullptr, *peer = nullptr;
     std::vector<uint32_t> hp((size_t)R * 4);
     for (uint32_t r = 0; r < R; ++r) {
-        hp[r * 4 + 0] = s->n_chunks;
-        hp[r * 4 + 1] = s->desc.id_base + r * (uint32_t)s->n;
+        hp[r * 4 + 0] = ranks[r].n_chunks;
+        hp[r * 4 + 1] = ranks[r].id_base;
         hp[r * 4 + 2] = F;
     }
     hipError_t e = hipMalloc((void**)&gmask, (uint64_t)R * F * W * 8);
     if (e == hipSuccess) e = hipMemsetAsync(gmask, 0, (uint64_t)R * F * W * 8, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc((void**)&gtile, (uint64_t)F * R * s->g_tiles * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&gtile, (uint64_t)F * R * out->g_tiles * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&peer, (size_t)R * 16);
-    if (e == hipSuccess) e = hipMemcpy(peer, hp.data(), (size_t)R * 16, hipMemcpyHostToDevice);
-    for (uint32_t r = 0; r < R && e == hipSuccess; ++r)
-        e = hipMemcpy2DAsync(gmask + (uint64_t)r * F * W, (size_t)W * 8, s->last_mask, (size_t)s->n_chunks * 8, (size_t)s->n_chunks * 8, F,
-                             hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(peer, hp.data(), (size_t)R * 16, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // hp is a host temporary
+    for (uint32_t r = 0; r < R && e == hipSuccess; ++r)  // the copy yh_allgather_draw_lists_async makes into send_pad
+        e = hipMemcpy2DAsync(gmask + (uint64_t)r * F * W, (size_t)W * 8, ranks[r].words, (size_t)ranks[r].n_chunks * 8,
+                             (size_t)ranks[r].n_chunks * 8, F, hipMemcpyDeviceToDevice, ctx->stream);
     for (uint32_t f = 0; f < F && e == hipSuccess; ++f) {
         const uint64_t cap = (uint64_t)R * W * 64;
-        if (s->gathered_cap[f] < cap) {
-            if (s->gathered[f]) (void)hipFree(s->gathered[f]);
-            s->gathered[f] = nullptr;
-            s->gathered_cap[f] = 0;
-            e = hipMalloc((void**)&s->gathered[f], cap * 4);
-            if (e == hipSuccess) s->gathered_cap[f] = cap;
+        if (out->gathered_cap[f] < cap) {
+            if (out->gathered[f]) (void)hipFree(out->gathered[f]);
+            out->gathered[f] = nullptr;
+            out->gathered_cap[f] = 0;
+            e = hipMalloc((void**)&out->gathered[f], cap * 4);
+            if (e == hipSuccess) out->gathered_cap[f] = cap;
         }
     }
     int rc = YH_OK;
     if (e == hipSuccess) {
         // lend the buffers to the scene's gather fields for one expansion
-        s->gmask = gmask;
-        s->gtile = gtile;
-        s->d_peer = peer;
-        rc = gather_expand(s, gmask, F, ctx->stream);
+        out->gmask = gmask;
+        out->gtile = gtile;
+        out->d_peer = peer;
+        rc = gather_expand(out, gmask, F, ctx->stream);
         if (rc == YH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, YH_ERR_HIP, "yh_gather_selftest: expansion failed");
-        s->gmask = nullptr;
-        s->gtile = nullptr;
-        s->d_peer = nullptr;
-        s->gathered_async = rc == YH_OK;
+        out->gmask = nullptr;
+        out->gtile = nullptr;
+        out->d_peer = nullptr;
+        out->gathered_async = rc == YH_OK;
     }
-    s->g_ranks = 0;
-    s->g_words = s->g_tiles = 0;
+    out->g_ranks = 0;
+    out->g_words = out->g_tiles = 0;
     for (void* p : {(void*)gmask, (void*)gtile, (void*)peer})
         if (p) (void)hipFree(p);
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? YH_ERR_OOM : YH_ERR_HIP, "yh_gather_selftest: %s", hipGetErrorString(e));
     return rc;
+}
+
+// fake_ranks copies of this scene's own words, rank r pretending to own ids id_base + r * n_entities (what R identical
+// shards would have sent), rows three words longer than the scene's own (the zero padding).
+extern "C" int yh_gather_selftest(yh_scene* s, uint32_t fake_ranks) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_gather_selftest: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    ARG_TRY(ctx, fake_ranks >= 1 && fake_ranks <= 64, "yh_gather_selftest: 1..64 ranks");
+    if (ctx->comm || s->g_ready) return fail(ctx, YH_ERR_STATE, "yh_gather_selftest: not on a scene or context that gathers for real");
+    if (s->frames == 0 || s->last_n_frusta == 0 || !s->last_mask) return fail(ctx, YH_ERR_STATE, "yh_gather_selftest: no culling frame has run");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_scene(s)) return rc;
+    std::vector<FakeRank> ranks;
+    for (uint32_t r = 0; r < fake_ranks; ++r) ranks.push_back({s->last_mask, s->n_chunks, s->desc.id_base + r * (uint32_t)s->n});
+    return gather_selftest_run(s, ranks, s->last_n_frusta, 3);
+}
+
+// The same with R DIFFERENT shards: the scenes of one context (one per part of yh_partition_subtrees, each framed
+// with the same frusta) stand for the ranks, in rank order; every row keeps its own length and id base, the shorter
+// ones are padded.  The gathered lists land in shards[0] — what rank 0 would hold after the exchange.
+extern "C" int yh_gather_selftest_shards(yh_scene* const* shards, uint32_t n_shards) {
+    if (!shards || !n_shards || !shards[0]) return fail(nullptr, YH_ERR_BAD_ARG, "yh_gather_selftest_shards: NULL argument");
+    yh_scene* out = shards[0];
+    yh_ctx* ctx = out->ctx;
+    ARG_TRY(ctx, n_shards <= 64, "yh_gather_selftest_shards: 1..64 shards");
+    if (ctx->comm || out->g_ready) return fail(ctx, YH_ERR_STATE, "yh_gather_selftest_shards: not on a scene or context that gathers for real");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<FakeRank> ranks;
+    for (uint32_t r = 0; r < n_shards; ++r) {
+        yh_scene* s = shards[r];
+        ARG_TRY(ctx, s && s->ctx == ctx, "yh_gather_selftest_shards: every shard must be a scene of the same context");
+        if (s->frames == 0 || s->last_n_frusta == 0 || !s->last_mask)
+            return fail(ctx, YH_ERR_STATE, "yh_gather_selftest_shards: shard %u has run no culling frame", r);
+        ARG_TRY(ctx, s->last_n_frusta == out->last_n_frusta, "yh_gather_selftest_shards: the shards culled different numbers of frusta");
+        if (int rc = sync_scene(s)) return rc;
+        ranks.push_back({s->last_mask, s->n_chunks, s->desc.id_base});
+    }
+    return gather_selftest_run(out, ranks, out->last_n_frusta, 0);
 }
 
 // After a no-sync gather the host buffer holds running totals (ranks 0..r); turn them into per-rank counts once.
