@@ -640,3 +640,61 @@ def test_reported_kernel_names_are_kernels_of_the_library(ctx, oracle):
             ctx.wait()
     assert {"void k_frame_trs", "void k_frame_trs_big", "void k_frame_chain", "void k_frame_chain_big", "void k_frame_chain_x",
             "void k_frame_trs_x", "void k_level_mat4", "void k_chain_mat4"} <= seen, seen
+
+
+def test_planes_that_share_normals_are_culled_exactly_like_planes_tested_one_by_one(ctx, oracle):
+    """Frames whose planes share normals (cfg3's cascades: one light direction) are tested per distinct normal on the
+    device (cull_planned); the oracle tests every plane on its own.  Adversarial plane sets: exact duplicates, exactly
+    opposite normals, zero components of either sign, a NaN plane, eight identical frusta, planes that touch bounds
+    exactly (boundary flags) — lists, counts and boundary counts must be the oracle's."""
+    from yume_amd import Scene
+
+    n = 200_003
+    trs = oracle.synth_trs(n, n)
+    trs[0:3, :50] = 0.0  # a few unit boxes at the origin, unrotated: d = +-1 makes exact boundary / signed-zero cases
+    trs[3:6, :50] = 0.0
+    trs[6:10, :50] = 1.0
+    bounds = oracle.synth_aabb(n)
+    bounds[:50] = [-1, -1, -1, 1, 1, 1]
+    main = oracle.main_camera_planes().reshape(6, 4)
+    casc = oracle.cascade_planes().reshape(4, 6, 4)
+    rng = np.random.default_rng(5)
+
+    def slab(nrm, lo, hi):  # two opposite planes: lo <= n.x <= hi
+        nrm = np.asarray(nrm, np.float32)
+        return [np.concatenate([nrm, [np.float32(-lo)]]), np.concatenate([-nrm, [np.float32(hi)]])]
+
+    axis = slab([1, 0, 0], -30, 30) + slab([0, 1, 0], -20, 60) + slab([0, 0, 1], -90, 90)
+    axis_negzero = [p.copy() for p in axis]
+    for p in axis_negzero:
+        p[:3][p[:3] == 0] = -0.0  # the same normals with the other zero sign: must still group, must still agree
+    touching = slab([1, 0, 0], 1.0, 30) + slab([0, 1, 0], -1.0, -1.0) + slab([0, 0, 1], -90, 90)
+    nanp = [p.copy() for p in axis]
+    nanp[2][1] = np.nan
+    sets = {
+        "cascades + main": np.concatenate([main[None], casc]),
+        "eight identical frusta": np.repeat(main[None], 8, axis=0),
+        "axis slabs, zero signs mixed": np.stack([np.stack(axis), np.stack(axis_negzero), casc[1]]),
+        "touching planes": np.stack([np.stack(touching), np.stack(axis)]),
+        "a NaN normal component": np.stack([np.stack(nanp), np.stack(axis), np.stack(axis)]),
+        "one orthographic frustum": casc[2][None],
+        "shuffled plane order": np.stack([casc[0][rng.permutation(6)], casc[3][rng.permutation(6)], main[rng.permutation(6)]]),
+    }
+    flat_par, flat_lo = np.full(n, 0xFFFFFFFF, np.uint32), np.array([0, n], np.uint32)
+    world = oracle.frame_trs(trs, flat_par, flat_lo, n_threads=8)
+    with Scene(ctx, n, n_frusta=8) as s:
+        s.upload_flat()
+        s.upload_trs(trs)
+        s.upload_aabb(np.ascontiguousarray(bounds[:, :3].T), np.ascontiguousarray(bounds[:, 3:].T))
+        for name, planes in sets.items():
+            planes = np.ascontiguousarray(planes, np.float32).reshape(-1, 24)
+            F = planes.shape[0]
+            s.frame(planes)
+            with np.errstate(all="ignore"):
+                vis, bnd = oracle.cull(world, bounds, planes, n_threads=8)
+            counts, bcounts = s.counts()
+            for f in range(F):
+                assert np.array_equal(s.draw_list(f), np.flatnonzero(vis[f]).astype(np.uint32)), (name, f)
+                assert bcounts[f] == np.count_nonzero(bnd[f]), (name, f, "boundary count")
+            if name == "touching planes":
+                assert bcounts[0] > 0, "the touching set is meant to produce boundary cases"

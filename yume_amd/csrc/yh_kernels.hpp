@@ -48,6 +48,7 @@ struct FrameArgs {
     uint32_t n_meshes;
     float root[16];
     float planes[YH_K_MAX_FRUSTA * 24];
+    CullPlan plan;  // the same planes grouped by normal, when some share one (n_normals = 0: not in use)
 };
 
 // ---- chunked-plane addressing -------------------------------------------------------------------------
@@ -117,6 +118,14 @@ __device__ __forceinline__ void cull_entity(const FrameArgs& a, const M4& w, con
         for (int p = 0; p < 6; ++p) b[p] = a.bounds[mesh * 6u + p];
     }
     const CullBox box = cull_box(w, b[0], b[1], b[2], b[3], b[4], b[5]);
+    if (a.plan.n_normals) {  // wave-uniform: planes that share normals are tested per normal (yh_math.hpp cull_planned)
+        float min_abs;
+        uint32_t acc = cull_planned<false>(w, box, a.plan, min_abs);
+        if (__ballot(min_abs < 1e-5f)) acc = cull_planned<true>(w, box, a.plan, min_abs);  // some lane holds a boundary case: rare
+        vmask |= ~acc & ((1u << a.n_frusta) - 1u);
+        bmask |= (acc >> 8) & 0xFFu;
+        return;
+    }
 #pragma unroll 1
     for (uint32_t f = 0; f < a.n_frusta; ++f) {
         const uint32_t r = cull_frustum(w, box, &a.planes[f * 24]);
@@ -184,19 +193,65 @@ __device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* s_red) {
     return r;
 }
 
+// Expansion loop of one wave over its run of words (lane i of m_lo / m_hi holds word i, i < n_words): entry j of the
+// run's stretch of the list, out[j], is id0 + 64 * i + (bit index) of the j-th set bit.  Written out in ISA because
+// the loop is bound by instruction ISSUE, scalar and vector alike: per word two v_readlane bring the word to the
+// scalar unit, EXEC is narrowed to the word itself (no lane tests its own bit), v_mbcnt gives the rank among the set
+// bits, one v_add_lshl the byte offset from the scalar running position, one v_lshl_add the entity id, and ONE store
+// writes them; s_bcnt1 advances the position.  6 vector + 8 scalar instructions per non-zero word, 2 + 6 per zero
+// word (round 1: 14 vector instructions per word and two LDS reads; a first C++ version of this loop: 6 vector but
+// 19 scalar ones - address arithmetic, EXEC save/restore and the capacity test per word - and the ONE scalar unit of
+// a CU made it slower than before).  Every wave that gets here has all 64 lanes active (whole 256-thread workgroups,
+// wave-uniform exits only), so EXEC is simply set to the word and restored before the block ends; vector stores only.
+__device__ __forceinline__ void expand_run(uint32_t* out /* uniform: the run's first list entry */, uint32_t m_lo, uint32_t m_hi,
+                                           uint32_t n_words /* uniform */, uint32_t id0) {
+    uint64_t saved;
+    uint32_t lo, hi, i, pos, cnt, rank, off, id;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        "s_mov_b32 %[i], 0\n\t"
+        "s_mov_b32 %[pos], 0\n"
+        "yh_expand_loop_%=:\n\t"
+        "v_readlane_b32 %[lo], %[mlo], %[i]\n\t"
+        "v_readlane_b32 %[hi], %[mhi], %[i]\n\t"
+        "s_nop 0\n\t"
+        "s_mov_b32 exec_lo, %[lo]\n\t"
+        "s_mov_b32 exec_hi, %[hi]\n\t"
+        "s_cbranch_execz yh_expand_skip_%=\n\t"
+        "v_mbcnt_lo_u32_b32 %[rank], exec_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[rank], exec_hi, %[rank]\n\t"
+        "v_lshl_add_u32 %[id], %[i], 6, %[id0]\n\t"
+        "v_add_lshl_u32 %[off], %[rank], %[pos], 2\n\t"
+        "s_bcnt1_i32_b64 %[cnt], exec\n\t"
+        "global_store_dword %[off], %[id], %[out]\n\t"
+        "s_add_u32 %[pos], %[pos], %[cnt]\n"
+        "yh_expand_skip_%=:\n\t"
+        "s_add_u32 %[i], %[i], 1\n\t"
+        "s_cmp_lt_u32 %[i], %[n]\n\t"
+        "s_cbranch_scc1 yh_expand_loop_%=\n\t"
+        "s_mov_b64 exec, %[saved]"
+        : [saved] "=&s"(saved), [lo] "=&s"(lo), [hi] "=&s"(hi), [i] "=&s"(i), [pos] "=&s"(pos), [cnt] "=&s"(cnt),
+          [rank] "=&v"(rank), [off] "=&v"(off), [id] "=&v"(id)
+        : [mlo] "v"(m_lo), [mhi] "v"(m_hi), [n] "s"(n_words), [id0] "v"(id0), [out] "s"(out)
+        : "memory", "scc");
+}
+
+// Expansion of one tile of visibility words into its stretch of the ordered list.  Every wave owns a CONTIGUOUS run of
+// the tile's words: lane l loads word l of the run (one coalesced load), the run's words then come back one at a time
+// as wave-uniform values (v_readlane), so the running output position lives on the scalar unit (expand_run).
 __device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t t, const uint32_t f) {
     __shared__ uint32_t s_red[4];
-    __shared__ uint32_t s_off[YH_BLOCK];
-    __shared__ uint64_t s_mask[YH_BLOCK];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    __shared__ uint32_t s_wave[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t* __restrict__ masks = x.vismask + (uint64_t)f * x.n_chunks;
     const uint32_t c0 = t * x.words;
-    const uint32_t c = c0 + tid;
-    const uint64_t m = (tid < x.words && c < x.n_chunks) ? masks[c] : 0ull;
-    const uint32_t pc = (uint32_t)__popcll(m);
+    const uint32_t wpw = x.words >> 2;      // words per wave: 8, 16 or 64
+    const uint32_t cw = c0 + wv * wpw;      // first word of this wave's run
+    const uint64_t m = (lane < wpw && cw + lane < x.n_chunks) ? masks[cw + lane] : 0ull;
     // base = visible entities in the tiles before this one
     uint32_t part = 0;
-    if (x.self_count) {  // 16 byte-counts per load; c0 is a multiple of 64
+    if (x.self_count) {  // 16 byte-counts per load; c0 is a multiple of 32
         const uint4* __restrict__ c16 = reinterpret_cast<const uint4*>(x.viscnt + (uint64_t)f * x.cnt_stride);
         for (uint32_t i = tid; i < c0 / 16; i += YH_BLOCK) {
             const uint4 v = c16[i];
@@ -210,21 +265,15 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t 
         for (uint32_t i = tid; i < t; i += YH_BLOCK) part += cnt[i];
     }
     const uint32_t base = block_sum_256(part, s_red);
-    // exclusive scan of the 256 popcounts
-    uint32_t inc = pc;
+    // visible entities of each wave's run
+    uint32_t run = (uint32_t)__popcll(m);
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_up(inc, o);
-        if ((int)lane >= o) inc += v;
-    }
-    if (lane == 63) s_red[wv] = inc;
-    s_mask[tid] = m;
+    for (int o = 32; o > 0; o >>= 1) run += __shfl_xor(run, o);
+    if (lane == 0) s_wave[wv] = run;
     __syncthreads();
-    uint32_t wbase = 0;
-    for (uint32_t w = 0; w < wv; ++w) wbase += s_red[w];
-    s_off[tid] = wbase + inc - pc;
-    const uint32_t own = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wv; ++w) before += s_wave[w];
+    const uint32_t own = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     if (tid == 0) {
         if (t == 0 && f == 0)  // all of them: the frame that uses this set next may cull more frusta than this one
             for (uint32_t q = 0; q < YH_K_MAX_FRUSTA; ++q) x.bcount_next[q] = 0;
@@ -234,16 +283,25 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t 
             x.host_counts[YH_K_MAX_FRUSTA + f] = x.bcount_cur[f];
         }
     }
-    if (own == 0) return;
+    if (run == 0) return;  // (wave-uniform after the reduction)
     uint32_t* __restrict__ out = x.draw[f];
-    const uint32_t n_words = min(x.words, x.n_chunks - c0);
-#pragma unroll 8
-    for (uint32_t k = wv; k < n_words; k += 4) {
-        const uint64_t mk = s_mask[k];  // wave-uniform
-        if (mk) {
-            const uint64_t pos = (uint64_t)base + s_off[k] + lane_rank(mk);
-            if (((mk >> lane) & 1ull) && pos < x.draw_cap) out[pos] = ((c0 + k) << 6) + lane + x.id_base;
-        }
+    uint32_t pos = __builtin_amdgcn_readfirstlane(base + before);  // scalar: list position of the run's next entry
+    const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
+    const uint32_t id0 = (cw << 6) + lane + x.id_base;
+    const uint32_t n_words = min(wpw, x.n_chunks > cw ? x.n_chunks - cw : 0u);
+    // (entity counts stay below 2^31: positions and the capacity compare in 32 bits)
+    const uint32_t cap = x.draw_cap > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)x.draw_cap;
+    if (n_words == 0) return;
+    if (pos + run <= cap) {  // the whole run fits the list: the issue-lean loop
+        expand_run(out + pos, m_lo, m_hi, n_words, id0);
+        return;
+    }
+    for (uint32_t i = 0; i < n_words; ++i) {  // the list overflows inside this run: every lane checks its own entry
+        const uint32_t lo = __builtin_amdgcn_readlane(m_lo, i), hi = __builtin_amdgcn_readlane(m_hi, i);
+        const uint64_t word = ((uint64_t)hi << 32) | lo;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+        if (((word >> lane) & 1ull) && pos + rank < cap) out[pos + rank] = id0 + (i << 6);
+        pos += (uint32_t)__popcll(word);
     }
 }
 

@@ -287,6 +287,82 @@ YH_HD uint32_t cull_frustum(const M4& m, const CullBox& b, const float* __restri
     return (vis ? 1u : 0u) | (bnd ? 2u : 0u);
 }
 
+// The same test with the work that planes SHARE done once (cfg3: the four shadow cascades look along one light
+// direction, so their 24 planes have 3 distinct normals up to sign; the planes differ only in d).  Everything of a
+// plane's test except "+ d" depends on its normal alone:
+//     s = ((a*cwx + b*cwy) + c*cwz) + d   = p(n) + d          r = r(n)          t = s + r
+// and for the opposite normal -n both p and r come out as exactly -p and r (IEEE negation is exact and rounding is
+// symmetric; only the sign of a zero can differ, which no comparison below sees).  The host groups the frame's planes
+// by normal (yume_hip.hip build_cull_plan): per distinct normal one evaluation of p and r, per plane
+// t = fma(sgn, p, d) + r with sgn = +-1 — the product is exact, so the fused form rounds once, exactly like
+// (sgn*p) + d — and the two comparisons.  Bit for bit the visible / boundary flags of cull_frustum on every plane.
+struct CullPlanNormal {
+    float a, b, c;
+    uint32_t mid_end;  // planes [end of the previous normal, mid) use this normal, [mid, end) its negation; mid | end << 16
+};
+struct CullPlanPlane {
+    float d;
+    uint32_t frustum;
+};
+#define YH_PLAN_MAX_PLANES 48
+struct CullPlan {
+    uint32_t n_normals;  // 0: no plan, every plane is tested on its own (cull_frustum)
+    uint32_t pad[3];
+    CullPlanNormal normal[YH_PLAN_MAX_PLANES];
+    CullPlanPlane plane[YH_PLAN_MAX_PLANES];
+};
+
+// WITH_BOUNDARY = false: bit f of the result = NOT visible in frustum f, and min_abs = the smallest |t| met on any
+// plane (NaNs skipped, as `fabs(NaN) < 1e-5` is false): a boundary case exists iff min_abs < 1e-5, which is rare (a
+// handful per 16M entities), so the per-frustum boundary flags are only worked out — by a second pass with
+// WITH_BOUNDARY = true, bits [8, 16) — by waves that hold one.  One plane costs six vector instructions this way
+// (add or subtract, add, compare, select, shift-or, min) instead of ten.
+// min(lo, |t|) with a NaN t skipped.  On the device one v_min_f32 with the |.| source modifier (written out: the
+// compiler would first re-canonicalise the loop-carried `lo`, one more instruction per plane); t comes out of an
+// addition, so it is never a signalling NaN.
+YH_HD float min_abs_f32(float lo, float t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_min_f32 %0, %0, |%1|" : "+v"(lo) : "v"(t));
+    return lo;
+#else
+    return __builtin_fminf(lo, __builtin_fabsf(t));
+#endif
+}
+
+template <bool WITH_BOUNDARY>
+YH_HD uint32_t cull_planned(const M4& m, const CullBox& b, const CullPlan& plan, float& min_abs) {
+    uint32_t acc = 0;
+    uint32_t k = 0;
+    float lo = __builtin_inff();
+#pragma unroll 1
+    for (uint32_t j = 0; j < plan.n_normals; ++j) {
+        const float a = plan.normal[j].a, bb = plan.normal[j].b, c = plan.normal[j].c;
+        const uint32_t mid = plan.normal[j].mid_end & 0xFFFFu, end = plan.normal[j].mid_end >> 16;
+        const float p = a * b.cwx + bb * b.cwy + c * b.cwz;
+        const float ri = __builtin_fabsf(a * m.v[0] + bb * m.v[1] + c * m.v[2]);
+        const float rj = __builtin_fabsf(a * m.v[4] + bb * m.v[5] + c * m.v[6]);
+        const float rk = __builtin_fabsf(a * m.v[8] + bb * m.v[9] + c * m.v[10]);
+        const float r = ri * b.hx + rj * b.hy + rk * b.hz;
+        // (two loops, so that the sign choice costs no instruction: d - p = (-p) + d exactly)
+#define YH_PLAN_TEST(T_EXPR)                                                                              \
+    {                                                                                                     \
+        const float d = plan.plane[k].d;                                                                  \
+        const float t = (T_EXPR) + r;                                                                     \
+        const uint32_t f = plan.plane[k].frustum;                                                         \
+        acc |= ((t >= 0.0f) ? 0u : 1u) << f;                                                              \
+        if (WITH_BOUNDARY) acc |= ((__builtin_fabsf(t) < 1e-5f) ? 256u : 0u) << f;                        \
+        else lo = min_abs_f32(lo, t);                                                                     \
+    }
+#pragma unroll 1
+        for (; k < mid; ++k) YH_PLAN_TEST(p + d)
+#pragma unroll 1
+        for (; k < end; ++k) YH_PLAN_TEST(d - p)
+#undef YH_PLAN_TEST
+    }
+    min_abs = lo;
+    return acc;
+}
+
 // ---- synthetic scene generator -------------------------------------------------------
 YH_HD uint64_t yh_mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;

@@ -111,6 +111,7 @@ struct yh_scene {
     bool frame_pending = false;
     uint32_t last_n_frusta = 0;
     uint32_t n_meshes = 0;
+    bool use_cull_plan = true;  // group planes by normal when some share one (YH_NO_CULL_PLAN=1 in the environment: A/B runs)
     uint32_t max_mesh_id = 0;  // largest id ever uploaded (ids start out as 0): the table may not shrink below it
     float root[16];
     uint32_t root_dirty = 1;  // world.set(scene_root, WorldTransform{IDENTITY}) -> dirty (GameApp.zig:95)
@@ -415,6 +416,7 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
         scene_free(s);
         return code;
     }
+    if (const char* v = getenv("YH_NO_CULL_PLAN")) s->use_cull_plan = !(v[0] == '1');
     ctx->scenes.push_back(s);
     *out = s;
     return YH_OK;
@@ -1005,6 +1007,58 @@ static int ensure_kev(yh_scene* s) {
     return YH_OK;
 }
 
+// Groups a frame's planes by normal for cull_planned (yh_math.hpp): two planes share a group when their normals are
+// equal component by component, or exactly opposite (== on floats: +0 and -0 are the same normal, a NaN component
+// makes a plane a group of its own).  Left alone (n_normals = 0, the kernels test plane by plane) when no two planes
+// share a normal: the plan saves nothing then.
+static void build_cull_plan(const float* planes, uint32_t n_frusta, CullPlan& plan) {
+    memset(&plan, 0, sizeof plan);
+    const uint32_t P = n_frusta * 6;
+    if (P > YH_PLAN_MAX_PLANES) return;
+    int group_of[YH_PLAN_MAX_PLANES];
+    float sgn_of[YH_PLAN_MAX_PLANES];
+    uint32_t rep[YH_PLAN_MAX_PLANES], n_groups = 0;
+    for (uint32_t i = 0; i < P; ++i) {
+        const float* n = planes + 4 * i;
+        group_of[i] = -1;
+        for (uint32_t g = 0; g < n_groups && group_of[i] < 0; ++g) {
+            const float* m = planes + 4 * rep[g];
+            if (n[0] == m[0] && n[1] == m[1] && n[2] == m[2]) {
+                group_of[i] = (int)g;
+                sgn_of[i] = 1.0f;
+            } else if (n[0] == -m[0] && n[1] == -m[1] && n[2] == -m[2]) {
+                group_of[i] = (int)g;
+                sgn_of[i] = -1.0f;
+            }
+        }
+        if (group_of[i] < 0) {
+            rep[n_groups] = i;
+            group_of[i] = (int)n_groups++;
+            sgn_of[i] = 1.0f;
+        }
+    }
+    if (n_groups == P) return;
+    uint32_t k = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const float* m = planes + 4 * rep[g];
+        plan.normal[g].a = m[0];
+        plan.normal[g].b = m[1];
+        plan.normal[g].c = m[2];
+        uint32_t mid = 0;
+        for (float sgn : {1.0f, -1.0f}) {  // the planes on the normal itself first, then those on its negation
+            for (uint32_t i = 0; i < P; ++i)
+                if (group_of[i] == (int)g && sgn_of[i] == sgn) {
+                    plan.plane[k].d = planes[4 * i + 3];
+                    plan.plane[k].frustum = i / 6;
+                    ++k;
+                }
+            if (sgn > 0) mid = k;
+        }
+        plan.normal[g].mid_end = mid | (k << 16);
+    }
+    plan.n_normals = n_groups;
+}
+
 // Where the stage-3 scratch of one frame lies inside the static array (yh_frame_static): 32 counter words (only
 // [8, 24) are used: the boundary counters and the set k_expand zeroes), tile counts, visibility words, byte counts.
 struct StaticLayout {
@@ -1098,6 +1152,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
     a.n_meshes = s->n_meshes;
     memcpy(a.root, s->root, sizeof a.root);
     if (cull) memcpy(a.planes, planes, (size_t)n_frusta * 24 * sizeof(float));
+    if (cull && s->use_cull_plan) build_cull_plan(planes, n_frusta, a.plan);
     const int bounds = cull ? (int)s->desc.bounds_kind : 0;
     // XCD-aware tile order (xcd_tile), as measured: the launch of a flat scene gives every XCD one contiguous run of
     // tiles (256M instances 4.98 -> 4.77 ms; runs of 64-512 tiles do the same, runs of 8 are slower than no mapping);
