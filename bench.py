@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--force-comm", action="store_true",
                     help="rehearsal on one GPU: bring up a one-rank RCCL communicator and run the multi-GPU step "
                          "(frame + pipelined all-gather) - measures what the exchange adds to a frame")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="rehearsal on one GPU: partition each hierarchy as for this many GPUs and run shard 0")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not hand HIP events to the launches")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -220,6 +222,21 @@ def profiled_traffic(workload, symbol):
     return None, None
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on stdout when a communicator comes up; the bench's stdout carries ONE JSON line,
+    so communicator set-up runs with file descriptor 1 pointed at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 class Job:
     """What every workload of this process shares: the context, the ranks, the transport."""
 
@@ -275,12 +292,43 @@ def run_workload(job, name, steps, warmup, headline, entities=0):
     F = planes.shape[0]
 
     ctx = job.ctx
-    lo = synth.level_offsets(n, wl["levels"])
-    parent = synth.parents(lo, index_base=rank * n)
+    ranks = max(world_size, args.emulate_ranks)
+    sharding = None
+    if ranks > 1 and wl["levels"] > 1:
+        # A hierarchy shards by subtree-closed ranges: ONE tree of n x ranks entities, cut by the
+        # library's partitioner into one part per GPU, this rank's part extracted into its own depth-sorted arrays;
+        # its entities draw their synthetic values from their GLOBAL indices, emitted ids are shard_base + local.
+        from yume_amd import shard
+
+        t0 = time.perf_counter()
+        glo = synth.level_offsets(n * ranks, wl["levels"])
+        gpar = synth.parents(glo)
+        t1 = time.perf_counter()
+        part_of, sizes = shard.partition_subtrees(gpar, glo, ranks)
+        t2 = time.perf_counter()
+        parent, lo, g_of_l = shard.shard_extract(gpar, glo, part_of, rank, sizes[rank])
+        t3 = time.perf_counter()
+        del gpar, part_of
+        n = int(sizes[rank])
+        total = int(sizes.sum()) if world_size > 1 else n  # (a one-GPU rehearsal processes shard 0 only)
+        id_base = int(sizes[:rank].sum())
+        sharding = {"ranks": ranks, "global_entities": int(sizes.sum()), "part_sizes": [int(x) for x in sizes],
+                    "host_s": {"build_global_tree_numpy": round(t1 - t0, 3), "yh_partition_subtrees": round(t2 - t1, 3),
+                               "yh_shard_extract": round(t3 - t2, 3)},
+                    "note": "one-time set-up on the host, single thread, outside the timed region"
+                            + ("" if world_size > 1 else f"; rehearsal on one GPU: shard 0 of {ranks}")}
+    else:
+        # flat scenes shard by contiguous equal ranges: rank r owns global entities [r n, (r + 1) n)
+        lo = synth.level_offsets(n, wl["levels"])
+        parent = synth.parents(lo, index_base=rank * n)
+        g_of_l, id_base = None, rank * n
     scene = Scene(ctx, n, n_levels=wl["levels"], n_frusta=F, bounds_kind=wl["bounds"],
-                  max_meshes=16 if wl["bounds"] == 2 else 0, id_base=rank * n)
+                  max_meshes=16 if wl["bounds"] == 2 else 0, id_base=id_base)
     scene.upload_hierarchy(parent, lo)
-    scene.fill_synthetic(index_base=rank * n)  # inputs generated straight into HBM
+    if g_of_l is not None:
+        scene.fill_synthetic(global_of_local=g_of_l)  # inputs generated straight into HBM, from global indices
+    else:
+        scene.fill_synthetic(index_base=rank * n)
     scene.set_grouping(args.grouping)
     flags = _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC
 
@@ -288,7 +336,8 @@ def run_workload(job, name, steps, warmup, headline, entities=0):
     gather = world_size > 1 or args.force_comm
     if world_size == 1 and args.force_comm:
         if not job.comm_up:
-            ctx.comm_init(1, 0, Context.comm_unique_id())
+            with stdout_to_stderr():
+                ctx.comm_init(1, 0, Context.comm_unique_id())
             job.comm_up = True
         collective = "rccl (library, collective stream), one-rank rehearsal"
     if world_size > 1:
@@ -297,16 +346,17 @@ def run_workload(job, name, steps, warmup, headline, entities=0):
         dist, torch = job.dist, job.torch
         err = ""
         try:
-            if not job.comm_up and job.use_lib_comm:
-                ids = [Context.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                ctx.comm_init(world_size, rank, ids[0])
-                job.comm_up = True
-            if job.use_lib_comm:
-                scene.frame(planes, _lib.YH_FRAME_ALL_DIRTY)
-                scene.allgather_draw_lists()        # exact-size exchange (host sync): checks the communicator end to end
-                scene.allgather_draw_lists_async()  # the pipelined exchange the timed frames use
-                scene.gathered_counts(F)
+            with stdout_to_stderr():
+                if not job.comm_up and job.use_lib_comm:
+                    ids = [Context.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(ids, src=0)
+                    ctx.comm_init(world_size, rank, ids[0])
+                    job.comm_up = True
+                if job.use_lib_comm:
+                    scene.frame(planes, _lib.YH_FRAME_ALL_DIRTY)
+                    scene.allgather_draw_lists()        # exact-size exchange (host sync): checks the communicator end to end
+                    scene.allgather_draw_lists_async()  # the pipelined exchange the timed frames use
+                    scene.gathered_counts(F)
             ok = 1
         except Exception as ex:  # noqa: BLE001
             ok, err = 0, str(ex)
@@ -425,7 +475,8 @@ def run_workload(job, name, steps, warmup, headline, entities=0):
         "scaling": wl["scaling"],
         "config": {"workload": f"{name}: {wl['desc']}", "entities_per_gpu": n, "entities_total": total,
                    "levels": wl["levels"], "frusta": F, "launches_per_frame": int(len(groups)),
-                   "level_groups": [[int(x) for x in q] for q in groups], "kernels": names, "collective": collective},
+                   "level_groups": [[int(x) for x in q] for q in groups], "kernels": names, "collective": collective,
+                   "sharding": sharding},
         "roofline": roofline,
         "frame_hbm_frac": round((own_frame + lists_frame) / (ms_frame * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
         "frame_algorithmic_bytes_per_entity": round((own_frame + lists_frame) / n, 2),
@@ -473,7 +524,9 @@ def main():
         # one GPU per rank; a launcher that narrows each rank's visible devices to one leaves only index 0
         job.local_rank = job.local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(job.local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", job.local_rank))
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", job.local_rank))
+            dist.barrier()  # torch's own communicator comes up (and prints) here, not inside the first timed barrier
         job.dist = dist
     job.ctx = Context(job.local_rank)
     job.info = job.ctx.device_info()

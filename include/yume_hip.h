@@ -285,6 +285,9 @@ typedef struct yh_synth_desc {
 /* Fills TRS (and bounds) planes of the scene on the device from the counter-based generator; the
  * hierarchy must have been uploaded (level 0 and deeper levels draw from different ranges).              */
 int yh_scene_fill_synthetic(yh_scene* s, const yh_synth_desc* desc);
+/* The same for one shard of a partitioned scene: local entity e draws the values of global entity
+ * index_base + global_of_local[e] (yh_shard_extract's map), so the shards together hold exactly the unsharded scene. */
+int yh_scene_fill_synthetic_shard(yh_scene* s, const yh_synth_desc* desc, const uint32_t* global_of_local);
 int yh_download_trs(yh_scene* s, float* const planes[10], uint64_t first, uint64_t count);
 int yh_download_aabb(yh_scene* s, float* const min_planes[3], float* const max_planes[3], uint64_t first,
                      uint64_t count);

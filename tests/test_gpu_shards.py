@@ -53,6 +53,13 @@ def test_partition_shards_frames_and_gather_reproduce_the_unsharded_scene(ctx, o
             s.upload_trs(np.ascontiguousarray(trs[:, g]))
             b = bounds[g]
             s.upload_aabb(np.ascontiguousarray(b[:, :3].T), np.ascontiguousarray(b[:, 3:].T))
+        # the device-side generator fills a shard from its entities' GLOBAL indices: the same inputs as the upload
+        with Scene(ctx, int(sizes[0]), n_levels=levels, n_frusta=F) as filled:
+            filled.upload_hierarchy(*shard.shard_extract(par, lo, part_of, 0, sizes[0])[:2])
+            filled.fill_synthetic(seed=3, global_of_local=maps[0])
+            assert np.array_equal(filled.download_trs().view(np.uint32), np.ascontiguousarray(trs[:, maps[0]]).view(np.uint32))
+            mins, maxs = filled.download_aabb()
+            assert np.array_equal(np.concatenate([mins, maxs]).T, bounds[maps[0]])
         for s in scenes:
             s.frame(planes)
         if uneven:

@@ -137,6 +137,7 @@ SIGNATURES = {
     "yh_look_at": (None, [_vp, _vp, _vp, _vp]),
     "yh_camera_view_projection": (None, [_int, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
     "yh_scene_fill_synthetic": (_int, [_vp, C.POINTER(SynthDesc)]),
+    "yh_scene_fill_synthetic_shard": (_int, [_vp, C.POINTER(SynthDesc), _vp]),
     "yh_download_trs": (_int, [_vp, _vp, _u64, _u64]),
     "yh_download_aabb": (_int, [_vp, _vp, _vp, _u64, _u64]),
     "yh_partition_subtrees": (_int, [_vp, _vp, _u32, _u32, _vp, _vp]),

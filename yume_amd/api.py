@@ -167,9 +167,16 @@ class Scene:
         count = self.n - first if count is None else count
         self._ck(L.lib().yh_mark_dirty(self._h, int(local), int(world), first, count))
 
-    def fill_synthetic(self, seed=0x59554D45, index_base=0):
+    def fill_synthetic(self, seed=0x59554D45, index_base=0, global_of_local=None):
+        """Synthetic TRS / bounds generated on the device.  global_of_local (a shard's map to global slots): entity e
+        draws the values of global entity index_base + global_of_local[e]."""
         d = L.SynthDesc(seed, index_base)
-        self._ck(L.lib().yh_scene_fill_synthetic(self._h, C.byref(d)))
+        if global_of_local is None:
+            self._ck(L.lib().yh_scene_fill_synthetic(self._h, C.byref(d)))
+        else:
+            g = np.ascontiguousarray(global_of_local, np.uint32)
+            assert g.shape == (self.n,)
+            self._ck(L.lib().yh_scene_fill_synthetic_shard(self._h, C.byref(d), _ptr(g)))
         self.n_meshes = self.max_meshes
 
     def set_grouping(self, max_group_levels):

@@ -207,6 +207,14 @@ __device__ __forceinline__ void expand_run(uint32_t* out /* uniform: the run's f
                                            uint32_t n_words /* uniform */, uint32_t id0) {
     uint64_t saved;
     uint32_t lo, hi, i, pos, cnt, rank, off, id;
+    // the "s" operands must BE scalar registers (the compiler does not move a value it thinks divergent for us)
+    n_words = __builtin_amdgcn_readfirstlane(n_words);
+    // (readfirstlane returns a signed int: widen each half through uint32_t, or a low half with bit 31 set smears ones
+    // over the high half of the address)
+    const uint64_t o = (uint64_t)(uintptr_t)out;
+    const uint32_t o_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)o);
+    const uint32_t o_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(o >> 32));
+    out = (uint32_t*)(uintptr_t)(((uint64_t)o_hi << 32) | (uint64_t)o_lo);
     asm volatile(
         "s_mov_b64 %[saved], exec\n\t"
         "s_mov_b32 %[i], 0\n\t"
@@ -269,6 +277,7 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t 
     uint32_t run = (uint32_t)__popcll(m);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) run += __shfl_xor(run, o);
+    run = __builtin_amdgcn_readfirstlane(run);  // the same in every lane: say so, the branches below are then scalar
     if (lane == 0) s_wave[wv] = run;
     __syncthreads();
     uint32_t before = 0;
@@ -796,43 +805,34 @@ __global__ __launch_bounds__(YH_BLOCK) void k_gather_count(const GatherArgs g) {
 
 __global__ __launch_bounds__(YH_BLOCK) void k_gather_expand(const GatherArgs g) {
     __shared__ uint32_t s_red[4];
-    __shared__ uint32_t s_off[YH_BLOCK];
-    __shared__ uint64_t s_mask[YH_BLOCK];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    __shared__ uint32_t s_wave[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t t = blockIdx.x, f = blockIdx.y, r = blockIdx.z;
-    const uint32_t c0 = t * g.tile_words, c = c0 + tid;
-    const uint64_t m = (tid < g.tile_words && c < g.words) ? g.gmask[((uint64_t)r * g.n_frusta + f) * g.words + c] : 0ull;
-    const uint32_t pc = (uint32_t)__popcll(m);
+    const uint32_t wpw = g.tile_words >> 2;  // every wave owns a contiguous run of the tile's words (as expand_tile)
+    const uint32_t cw = t * g.tile_words + wv * wpw;
+    const uint64_t m = (lane < wpw && cw + lane < g.words) ? g.gmask[((uint64_t)r * g.n_frusta + f) * g.words + cw + lane] : 0ull;
     // base = entries of the ranks before this one and of this rank's tiles before this one
     const uint32_t* __restrict__ cnt = g.gtile + (uint64_t)f * g.n_ranks * g.n_tiles;
-    const uint32_t before = r * g.n_tiles + t;
+    const uint32_t before_tiles = r * g.n_tiles + t;
     uint32_t part = 0;
-    for (uint32_t i = tid; i < before; i += YH_BLOCK) part += cnt[i];
+    for (uint32_t i = tid; i < before_tiles; i += YH_BLOCK) part += cnt[i];
     const uint32_t base = block_sum_256(part, s_red);
-    uint32_t inc = pc;
+    uint32_t run = (uint32_t)__popcll(m);
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_up(inc, o);
-        if ((int)lane >= o) inc += v;
-    }
-    if (lane == 63) s_red[wv] = inc;
-    s_mask[tid] = m;
+    for (int o = 32; o > 0; o >>= 1) run += __shfl_xor(run, o);
+    run = __builtin_amdgcn_readfirstlane(run);  // the same in every lane: say so, the branches below are then scalar
+    if (lane == 0) s_wave[wv] = run;
     __syncthreads();
-    uint32_t wbase = 0;
-    for (uint32_t w = 0; w < wv; ++w) wbase += s_red[w];
-    s_off[tid] = wbase + inc - pc;
-    const uint32_t own = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wv; ++w) before += s_wave[w];
+    const uint32_t own = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     if (tid == 0 && t + 1 == g.n_tiles) g.cum[r * YH_K_MAX_FRUSTA + f] = base + own;
-    if (own == 0) return;
-    uint32_t* __restrict__ out = g.out[f];
-    const uint32_t id_base = g.peer[r * 4 + 1];
-    const uint32_t n_words = min(g.tile_words, g.words - c0);
-#pragma unroll 8
-    for (uint32_t k = wv; k < n_words; k += 4) {
-        const uint64_t mk = s_mask[k];  // wave-uniform
-        if (mk && ((mk >> lane) & 1ull)) out[(uint64_t)base + s_off[k] + lane_rank(mk)] = ((c0 + k) << 6) + lane + id_base;
-    }
+    if (run == 0) return;  // wave-uniform
+    const uint32_t n_words = min(wpw, g.words > cw ? g.words - cw : 0u);
+    if (n_words == 0) return;
+    const uint32_t pos = __builtin_amdgcn_readfirstlane(base + before);
+    expand_run(g.out[f] + pos, (uint32_t)m, (uint32_t)(m >> 32), n_words, (cw << 6) + lane + g.peer[r * 4 + 1]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1042,10 +1042,12 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
 // the oracle's host generator.  Level 0 (local index < n_level0) draws from the wide ranges.
 __global__ __launch_bounds__(YH_BLOCK) void k_synth(float* __restrict__ trs, float* __restrict__ bounds,
                                                     uint32_t* __restrict__ mesh_id, uint32_t n_meshes, uint64_t n,
-                                                    uint64_t n_level0, uint64_t seed, uint64_t index_base) {
+                                                    uint64_t n_level0, uint64_t seed, uint64_t index_base,
+                                                    const uint32_t* __restrict__ global_of_local) {
     const uint64_t e = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;
     if (e >= n) return;
-    const uint64_t g = index_base + e;
+    // a shard draws entity e's values from its GLOBAL index, so that the shards of one scene hold the scene's data
+    const uint64_t g = index_base + (global_of_local ? (uint64_t)global_of_local[e] : e);
     const bool top = e < n_level0;
     const float tr = top ? 100.0f : 5.0f;
     float t[10];

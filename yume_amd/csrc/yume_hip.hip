@@ -1772,7 +1772,16 @@ extern "C" void yh_extract_planes(const float vp[16], float planes_out[24]) {
 }
 
 // ------------------------------------------------------------------------------------ synthetic scenes
-extern "C" int yh_scene_fill_synthetic(yh_scene* s, const yh_synth_desc* d) {
+static int fill_synthetic(yh_scene* s, const yh_synth_desc* d, const uint32_t* global_of_local);
+
+extern "C" int yh_scene_fill_synthetic(yh_scene* s, const yh_synth_desc* d) { return fill_synthetic(s, d, nullptr); }
+
+extern "C" int yh_scene_fill_synthetic_shard(yh_scene* s, const yh_synth_desc* d, const uint32_t* global_of_local) {
+    if (!global_of_local) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_scene_fill_synthetic_shard: global_of_local is NULL");
+    return fill_synthetic(s, d, global_of_local);
+}
+
+static int fill_synthetic(yh_scene* s, const yh_synth_desc* d, const uint32_t* global_of_local) {
     if (!s || !d) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_scene_fill_synthetic: NULL argument");
     if (!s->have_hierarchy) return fail(s->ctx, YH_ERR_STATE, "yh_scene_fill_synthetic: upload the hierarchy first");
     if (s->desc.local_kind != YH_LOCAL_TRS) return fail(s->ctx, YH_ERR_STATE, "yh_scene_fill_synthetic: TRS scenes only");
@@ -1789,10 +1798,17 @@ extern "C" int yh_scene_fill_synthetic(yh_scene* s, const yh_synth_desc* d) {
             }
         if (int rc = yh_upload_mesh_aabbs(s, t.data(), nm)) return rc;
     }
+    uint32_t* d_map = nullptr;
+    if (global_of_local) {  // the shard's global slots, through the staging buffer
+        if (int rc = sync_scene(s)) return rc;
+        if (int rc = ensure_staging(s, s->n * 4)) return rc;
+        d_map = (uint32_t*)s->staging;
+        HIP_TRY(s->ctx, hipMemcpyAsync(d_map, global_of_local, s->n * 4, hipMemcpyHostToDevice, s->ctx->stream));
+    }
     hipLaunchKernelGGL(k_synth, dim3(cdiv(s->n, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream, s->trs,
                        s->desc.bounds_kind == YH_BOUNDS_PER_ENTITY ? s->bounds : (float*)nullptr,
                        table ? s->mesh_id : (uint32_t*)nullptr, table ? s->n_meshes : 1u, s->n,
-                       (uint64_t)s->level_offsets[1], d->seed, d->index_base);
+                       (uint64_t)s->level_offsets[1], d->seed, d->index_base, (const uint32_t*)d_map);
     HIP_TRY(s->ctx, hipGetLastError());
     if (table) s->max_mesh_id = s->n_meshes - 1;  // k_synth draws ids from the whole table
     return sync_scene(s);
