@@ -114,6 +114,11 @@ const char* yh_last_error(const yh_ctx* ctx);             /* ctx may be NULL: la
 int yh_device_info_get(yh_ctx* ctx, yh_device_info* out);
 int yh_wait(yh_ctx* ctx);                                 /* drain the context's stream                    */
 void* yh_stream(yh_ctx* ctx);                             /* the hipStream_t all work is enqueued on       */
+/* Page-locked host memory for staging columns (the engine-side system copies flecs table rows into one depth-sorted
+ * column before yh_upload_*_aos68, ecs.zig:695-705 hands out per-table pointers only): copies to and from it run at
+ * link speed.  NULL when it cannot be had (yh_last_error); ordinary memory works everywhere, slower.            */
+void* yh_host_alloc(yh_ctx* ctx, uint64_t bytes);
+void yh_host_free(yh_ctx* ctx, void* p);
 
 /* ---- scene --------------------------------------------------------------------------------------------- */
 int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* desc, yh_scene** out);

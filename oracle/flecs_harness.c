@@ -31,7 +31,9 @@
  *            (GPU build: batches = slot-order rebuilds so far, rows_seen = entities in the device scene), then
  *            u64 rows_up, u64 rows_down = 68-byte rows that crossed PCIe in the frame, u64 walks, u64 walks_skipped
  *            (query iterations done / frames that reused the last one).  GPU build, env YFH_PLAIN=1: whole columns both
- *            ways every frame instead of the incremental mode; YFH_ALWAYS_WALK=1: iterate the query every frame.
+ *            ways every frame instead of the incremental mode; YFH_ALWAYS_WALK=1: iterate the query every frame;
+ *            YFH_NO_READBACK=1: rows stay on the device (setReadback(0)) until the last frame, which brings whole columns back;
+ *            YFH_VALIDATE=1: do not trust the structural-change observers, compare every cached table every frame.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -193,6 +195,10 @@ int main(int argc, char** argv) {
     }
     if (getenv("YFH_PLAIN")) GpuTransformCullSystem_setIncremental(gpu, 0);
     if (getenv("YFH_ALWAYS_WALK")) GpuTransformCullSystem_setSkipWalks(gpu, 0);
+    const int no_readback = getenv("YFH_NO_READBACK") != NULL; /* results stay on the device until the last frame */
+    if (no_readback) GpuTransformCullSystem_setReadback(gpu, 0);
+    if (getenv("YFH_THREADS")) GpuTransformCullSystem_setThreads(gpu, atoi(getenv("YFH_THREADS")));
+    if (getenv("YFH_VALIDATE")) GpuTransformCullSystem_setTrustObservers(gpu, 0); /* compare every table every frame */
     ecs_entity_t* vis = malloc(sizeof(ecs_entity_t) * n);
     uint32_t* vis_idx = malloc(sizeof(uint32_t) * n);
 #else
@@ -229,6 +235,9 @@ int main(int argc, char** argv) {
             ecs_modified_id(w, target, comp); /* -> onSet -> dirty */
         }
         g_batches = g_rows = 0;
+#ifdef USE_GPU_SYSTEM
+        if (no_readback && f + 1 == n_frames) GpuTransformCullSystem_setReadback(gpu, 1); /* the last frame catches flecs up */
+#endif
         struct timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
         /* PostUpdate: TransformSyncSystem, then its two dependents (ecs.zig:277-293) */

@@ -93,3 +93,28 @@ def test_oracle_equals_flecs_driven_systems(oracle, tmp_path, n, levels):
         assert rows == n  # every entity is matched (all live under the root, which owns a WorldTransform)
         # one flecs table per (ChildOf, parent): the oracle's batch grouping is the same partition of the rows
         assert batches == exp_batches, f"frame {fi}: {batches} flecs batches vs {exp_batches} oracle batches"
+
+
+def test_structural_change_observers_of_the_gpu_system_inside_real_flecs(tmp_path):
+    """GpuTransformCullSystem's clean frames trust its observers: every operation that lets rows enter, leave or move
+    inside a table with one of the transform components must raise its structure flag, nothing else may (CPU only: the
+    system is registered in the reference's flecs, never run)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flecs_o = os.path.join(root, "oracle", "_ref", "flecs.o")
+    flecs_h = "/root/reference/vendor/flecs"
+    lib = os.path.join(root, "yume_amd", "libyume_hip.so")
+    if not (os.path.exists(flecs_o) and os.path.exists(os.path.join(flecs_h, "flecs.h")) and os.path.exists(lib)):
+        pytest.skip("needs oracle/_ref/flecs.o (make -C oracle ref) and the reference's flecs.h")
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-DFLECS_CONFIG_HEADER=1", "-I", flecs_h, "-I", os.path.join(root, "yume_amd", "host"),
+                           "-I", os.path.join(root, "include"), "-o", str(exe), os.path.join(root, "tests", "flecs_structure_probe.c"),
+                           os.path.join(root, "yume_amd", "host", "GpuTransformCullSystem.c"), flecs_o, "-L", os.path.join(root, "yume_amd"),
+                           "-lyume_hip", f"-Wl,-rpath,{os.path.join(root, 'yume_amd')}", "-lm", "-lpthread"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    rows = [line.split() for line in r.stdout.splitlines()]
+    assert len(rows) == 13, r.stdout + r.stderr
+    for name, want, got in rows:
+        assert want == got, f"{name}: structure flag {got}, expected {want}"
+    assert r.returncode == 0

@@ -71,10 +71,10 @@ def reparent_arg(index):
     return m
 
 
-@pytest.mark.parametrize("plain,always_walk", [(False, False), (True, False), (False, True)],
-                         ids=["incremental", "whole-columns", "incremental-always-walk"])
+@pytest.mark.parametrize("plain,always_walk,validate", [(False, False, False), (True, False, False), (False, True, False), (False, False, True)],
+                         ids=["incremental", "whole-columns", "incremental-always-walk", "incremental-validate-every-frame"])
 @pytest.mark.parametrize("n,levels", [(10_000, 1), (4096, 8), (50_000, 6)])
-def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, levels, plain, always_walk):
+def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, levels, plain, always_walk, validate):
     rng = np.random.default_rng(n + levels)
     lo = oracle.synth_level_offsets(n, levels)
     par = oracle.synth_parents(lo)
@@ -113,6 +113,9 @@ def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, le
         env["YFH_PLAIN"] = "1"
     if always_walk:
         env["YFH_ALWAYS_WALK"] = "1"
+    env.pop("YFH_VALIDATE", None)
+    if validate:
+        env["YFH_VALIDATE"] = "1"
     subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
     cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
     gpu = read_out(out_g, n, len(frames), planes.shape[0], oracle.T68, gpu=True)
@@ -150,3 +153,56 @@ def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, le
         exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[idx]), np.ascontiguousarray(bounds[idx]), planes)
         for f in range(planes.shape[0]):
             assert np.array_equal(np.sort(vis[f]), idx[np.flatnonzero(exp_vis[f])]), f"frame {fi} frustum {f}: visible set"
+
+
+def test_results_can_stay_on_the_device_until_readback_is_switched_on(oracle, tmp_path):
+    """setReadback(0): nothing comes back (a device consumer reads matrices and lists where they are), the device stays
+    right frame after frame — visible sets of every frame, structural changes included — and the frame after readback is
+    switched on again leaves flecs' columns exactly as the CPU systems have them."""
+    n, levels = 30_000, 6
+    rng = np.random.default_rng(77)
+    lo = oracle.synth_level_offsets(n, levels)
+    par = oracle.synth_parents(lo)
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo[1])))
+    bounds = oracle.synth_aabb(n)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+
+    def rnd_m(scale=5.0):
+        return oracle.compose(rng.uniform(-scale, scale, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+
+    last = np.arange(int(lo[-2]), n)
+    doomed = rng.choice(last, 15, replace=False)
+    movers = np.setdiff1d(last, doomed)[:8]
+    frames = [[], [(int(e), 0, rnd_m()) for e in np.unique(rng.integers(0, n, 200))],
+              [(int(e), 1, rnd_m(50.0)) for e in np.unique(rng.integers(0, n, 100))],
+              [(-1, 1, oracle.compose([1, 2, 3], [0, 0.7071068, 0, 0.7071068], [2, 2, 2]))],
+              # a structural change while the host copies are stale, together with fresh edits of other rows
+              [(int(e), 2, np.zeros(16, np.float32)) for e in doomed] + [(int(e), 0, rnd_m()) for e in movers[:3]],
+              [(int(e), 3, reparent_arg(int(p))) for e, p in zip(movers, rng.integers(int(lo[-3]), int(lo[-2]), movers.size))],
+              [(int(movers[1]), 0, rnd_m())], []]
+    scene, out_c, out_g = tmp_path / "scene.bin", tmp_path / "cpu.bin", tmp_path / "gpu.bin"
+    write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
+    subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
+    env["YFH_NO_READBACK"] = "1"
+    subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
+    cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
+    gpu = read_out(out_g, n, len(frames), 1, oracle.T68, gpu=True)
+    alive = np.ones(n, bool)
+    for fi, ((cw, cl, _, rows, _), (gw, gl, _rebuilds, g_rows, vis)) in enumerate(zip(cpu, gpu)):
+        for e, kind, _m in frames[fi]:
+            if kind == 2:
+                alive[e] = False
+        assert g_rows == rows == alive.sum()
+        idx = np.flatnonzero(alive)
+        exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[idx]), np.ascontiguousarray(bounds[idx]), planes)
+        assert np.array_equal(np.sort(vis[0]), idx[np.flatnonzero(exp_vis[0])]), f"frame {fi}: visible set (device state)"
+        up, down, _walks, _skipped = vis[-1]
+        structural = any(kind in (2, 3) for _e, kind, _m in frames[fi])
+        if fi + 1 < len(frames):
+            assert down == 0 or structural or fi == 0, f"frame {fi}: rows came back although readback is off"
+        else:  # the last frame ran with readback on: whole columns came home
+            assert down == 2 * g_rows
+            with np.errstate(all="ignore"):
+                assert np.array_equal(gw["m"], cw["m"], equal_nan=True) and np.array_equal(gl["m"], cl["m"], equal_nan=True)
+            assert np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"])

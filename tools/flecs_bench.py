@@ -1,6 +1,6 @@
 """End-to-end frame time inside the REAL flecs (oracle/_ref harnesses): the reference's CPU systems against the GPU
 system, whole-column and incremental modes.  usage: python tools/flecs_bench.py [n] [levels]
-Frames: 0 everything dirty (first frame), 1 nothing dirty, 2 1 % local edits, 3 nothing dirty, 4 root moved."""
+Frames: 0 everything dirty (first frame), 1 nothing dirty, 2 1 % local edits, 3 nothing dirty, 4 root moved, 5 nothing dirty."""
 import os
 import subprocess
 import sys
@@ -23,15 +23,20 @@ bounds = oracle.synth_aabb(n)
 planes = oracle.main_camera_planes().reshape(1, 24)
 m = oracle.compose([1, 2, 3], [0, 0, 0, 1], [1, 1, 1])
 edits = [(int(e), 0, m) for e in np.unique(rng.integers(0, n, n // 100))]
-frames = [[], [], edits, [], [(-1, 1, oracle.compose([1, 2, 3], [0, 0.7071068, 0, 0.7071068], [2, 2, 2]))]]
+frames = [[], [], edits, [], [(-1, 1, oracle.compose([1, 2, 3], [0, 0.7071068, 0, 0.7071068], [2, 2, 2]))], []]
 with tempfile.TemporaryDirectory() as d:
     scene = os.path.join(d, "scene.bin")
     write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
     for label, binary, env in (("CPU systems (reference rule, real flecs)", CPU, {}),
                                ("GPU system, whole columns", GPU, {"YFH_PLAIN": "1"}),
-                               ("GPU system, incremental", GPU, {})):
+                               ("GPU system, incremental, every table validated every frame (round 1)", GPU, {"YFH_VALIDATE": "1"}),
+                               ("GPU system, incremental, 1 thread copies rows back", GPU, {"YFH_THREADS": "1"}),
+                               ("GPU system, incremental", GPU, {}),
+                               ("GPU system, incremental, results stay on the device (last frame reads all back)", GPU, {"YFH_NO_READBACK": "1"})):
         e = dict(os.environ, YFH_TIMES="1", **env)
-        e.pop("YFH_PLAIN", None) if "YFH_PLAIN" not in env else None
+        for k in ("YFH_PLAIN", "YFH_VALIDATE", "YFH_ALWAYS_WALK", "YFH_NO_READBACK", "YFH_THREADS"):
+            if k not in env:
+                e.pop(k, None)
         r = subprocess.run([binary, scene, os.path.join(d, "out.bin")], env=e, capture_output=True, text=True, timeout=1200)
         times = [line.split(": ")[1].split(" ms")[0] for line in r.stderr.splitlines() if line.startswith("frame ")]
-        print(f"{label:45s} n={n} L={levels}  ms per frame: " + "  ".join(times), flush=True)
+        print(f"{label:90s} n={n} L={levels}  ms per frame: " + "  ".join(times), flush=True)

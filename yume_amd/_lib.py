@@ -86,6 +86,8 @@ SIGNATURES = {
     "yh_device_info_get": (_int, [_vp, C.POINTER(DeviceInfo)]),
     "yh_wait": (_int, [_vp]),
     "yh_stream": (_vp, [_vp]),
+    "yh_host_alloc": (_vp, [_vp, _u64]),
+    "yh_host_free": (None, [_vp, _vp]),
     "yh_scene_create": (_int, [_vp, C.POINTER(SceneDesc), C.POINTER(_vp)]),
     "yh_scene_destroy": (None, [_vp]),
     "yh_upload_hierarchy": (_int, [_vp, _vp, _vp]),

@@ -282,6 +282,22 @@ extern "C" int yh_wait(yh_ctx* ctx) {
 
 extern "C" void* yh_stream(yh_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+// Page-locked host memory for the caller's staging columns (rows cross PCIe at link speed from it, and asynchronously).
+extern "C" void* yh_host_alloc(yh_ctx* ctx, uint64_t bytes) {
+    if (!ctx || !bytes) return nullptr;
+    void* p = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        fail(ctx, YH_ERR_OOM, "yh_host_alloc: %llu bytes of page-locked memory not available", (unsigned long long)bytes);
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void yh_host_free(yh_ctx* ctx, void* p) {
+    if (!p) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipHostFree(p);
+}
+
 // ------------------------------------------------------------------------------------------------ scene
 static void scene_free(yh_scene* s) {
     if (!s) return;

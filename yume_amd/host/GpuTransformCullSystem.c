@@ -22,10 +22,14 @@
  */
 #include "GpuTransformCullSystem.h"
 
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #define ROW 68u
+#define MAX_THREADS 32
+#define ROWS_PER_THREAD_MIN 8192u /* below this many changed rows per helper a thread costs more than it saves */
 
 typedef struct Batch {
     void* world_col;
@@ -94,13 +98,27 @@ struct GpuTransformCullSystem {
     /* incremental mode: only rows whose onSet fired go up, only rows the frame touched come back */
     int incremental;
     int skip_walks;          /* reuse the last walk of the query while nothing structural changed (default on) */
+    /* Structural-change tracking: observers on every id added to / removed from a table that holds one of the two
+     * components, and on such tables being created / deleted, raise structure_dirty.  While it is clear the batches of
+     * the last walk ARE the world's tables, row for row (nothing can enter, leave or move inside a table without one of
+     * those events), so a frame neither iterates the query nor validates any table: its cost is O(rows that changed). */
+    int structure_dirty;
+    int batches_live;        /* batches[] describe the tables as of the last structural event */
+    int trust_observers;     /* default on; off: every frame re-validates every cached table (round 1's behaviour) */
+    uint64_t frames_clean;   /* frames that touched no table at all */
+    ecs_entity_t root;       /* holder of the root WorldTransform (the Up source of level 0), from the last walk */
+    uint32_t* batch_of;      /* per slot: index into batches[] (O(1) instead of a binary search per changed run) */
+    int pinned;              /* stage_w / stage_l / slot_buf are page-locked (yh_host_alloc) */
+    int readback;            /* 1 (default): rows a frame changed come back into the flecs columns; 0: they stay on the device */
+    int host_stale;          /* frames ran without readback: the next frame with readback brings whole columns back */
+    int threads;             /* helpers for copying changed rows back into the tables (1 = the calling thread only) */
     Map slot_of;             /* entity -> slot, valid between rebuilds */
     ecs_entity_t* dirty[2];  /* [0] LocalTransform, [1] WorldTransform: entities set since the last frame */
     uint64_t n_dirty[2], cap_dirty[2];
     uint32_t* stamp[2];      /* per slot: frame in which the row was last queued (duplicates in the dirty lists) */
     uint32_t epoch;
     uint32_t* slot_buf;      /* n entries: slots of a sparse upload / of the changed rows */
-    ecs_entity_t observers[2];
+    ecs_entity_t observers[6];
     uint64_t last_up_rows, last_down_rows;
 
     int status;
@@ -234,6 +252,20 @@ static int same_as_last_walk(const GpuTransformCullSystem* s) {
     return memcmp(s->walk_entities, s->cached_entities, s->n * sizeof(ecs_entity_t)) == 0;
 }
 
+static void fill_batch_of(GpuTransformCullSystem* s);
+
+static void free_stage(GpuTransformCullSystem* s) {
+    if (s->pinned) {
+        yh_host_free(s->ctx, s->stage_w);
+        yh_host_free(s->ctx, s->stage_l);
+    } else {
+        free(s->stage_w);
+        free(s->stage_l);
+    }
+    s->stage_w = s->stage_l = NULL;
+    s->pinned = 0;
+}
+
 /* ---- rebuild of the slot order ----------------------------------------------------------------------------- */
 typedef struct KeyedBatch {
     uint32_t key;   /* slot of the batch's parent */
@@ -342,13 +374,21 @@ static int rebuild(GpuTransformCullSystem* s) {
         if ((rc = yh_scene_create(s->ctx, &d, &s->scene)) != YH_OK) goto done;
         s->scene_entities = n;
         s->scene_levels = n_levels;
-        uint8_t* w = (uint8_t*)realloc(s->stage_w, (size_t)n * ROW);
-        if (w) s->stage_w = w;
-        uint8_t* l = (uint8_t*)realloc(s->stage_l, (size_t)n * ROW);
-        if (l) s->stage_l = l;
+        /* the staging columns every row crosses PCIe through: page-locked, so the copies run at link speed */
+        free_stage(s);
+        s->stage_w = (uint8_t*)yh_host_alloc(s->ctx, (uint64_t)n * ROW);
+        s->stage_l = (uint8_t*)yh_host_alloc(s->ctx, (uint64_t)n * ROW);
+        s->pinned = s->stage_w && s->stage_l;
+        if (!s->pinned) { /* no page-locked memory to be had: ordinary memory works, slower */
+            free_stage(s);
+            s->stage_w = (uint8_t*)malloc((size_t)n * ROW);
+            s->stage_l = (uint8_t*)malloc((size_t)n * ROW);
+        }
         ecs_entity_t* eo = (ecs_entity_t*)realloc(s->entity_of_slot, (size_t)n * sizeof(ecs_entity_t));
         if (eo) s->entity_of_slot = eo;
-        if (!w || !l || !eo) {
+        uint32_t* bo = (uint32_t*)realloc(s->batch_of, (size_t)n * sizeof(uint32_t));
+        if (bo) s->batch_of = bo;
+        if (!s->stage_w || !s->stage_l || !eo || !bo) {
             rc = YH_ERR_OOM;
             goto done;
         }
@@ -359,6 +399,7 @@ static int rebuild(GpuTransformCullSystem* s) {
                sizeof(ecs_entity_t) * s->batches[b].count);
     s->n_levels = n_levels;
     s->bounds_stale = 1;
+    fill_batch_of(s);
     /* entity -> slot, and the per-slot buffers of the incremental mode */
     free(s->slot_of.e);
     s->slot_of.e = NULL;
@@ -465,6 +506,7 @@ static Batch* batch_cols(Batch* b) {
 
 /* batch holding a slot: binary search over the batches in slot order */
 static const Batch* batch_of_slot(GpuTransformCullSystem* s, uint32_t slot) {
+    if (s->batch_of) return batch_cols(&s->batches[s->batch_of[slot]]);
     uint32_t lo = 0, hi = s->n_batches - 1;
     while (lo < hi) {
         const uint32_t mid = (lo + hi + 1) / 2;
@@ -473,6 +515,31 @@ static const Batch* batch_of_slot(GpuTransformCullSystem* s, uint32_t slot) {
     }
     return batch_cols(&s->batches[s->order[lo]]);
 }
+
+/* slot -> batch table; rebuilt whenever slots are (re)assigned */
+static void fill_batch_of(GpuTransformCullSystem* s) {
+    if (!s->batch_of) return;
+    for (uint32_t b = 0; b < s->n_batches; ++b)
+        for (uint32_t r = 0; r < s->batches[b].count; ++r) s->batch_of[s->batches[b].slot_begin + r] = b;
+}
+
+/* Structural events: an id came to or left a table that holds one of the two components (entities created, deleted,
+ * re-parented, or moved between archetypes by an unrelated component: in each case rows enter, leave or move inside
+ * tables this system has cached), or such a table was created or deleted. */
+static void note_structure(ecs_iter_t* it) {
+    GpuTransformCullSystem* s = (GpuTransformCullSystem*)it->ctx;
+    if (s->structure_dirty) return;
+    const ecs_table_t* tables[2] = {it->table, it->other_table};
+    for (int k = 0; k < 2; ++k) {
+        if (!tables[k]) continue;
+        if (ecs_table_get_column_index(it->real_world, tables[k], s->local_id) >= 0 ||
+            ecs_table_get_column_index(it->real_world, tables[k], s->world_id) >= 0) {
+            s->structure_dirty = 1;
+            return;
+        }
+    }
+}
+static void note_table(ecs_iter_t* it) { ((GpuTransformCullSystem*)it->ctx)->structure_dirty = 1; }
 
 /* OnSet observers: the same events that run the components' onSet hooks */
 static void note_set(ecs_iter_t* it, int k) {
@@ -535,45 +602,156 @@ static int restore_walk(GpuTransformCullSystem* s, const ecs_iter_t* it) {
     return 1;
 }
 
+/* Changed rows [i0, i1) of the staging columns (ascending slots) back into their tables: runs of consecutive slots
+ * inside one batch go in one copy.  Touches no shared state but the rows themselves (column pointers that are not
+ * cached yet are looked up, not cached: several helpers may meet in one batch), so ranges can run side by side. */
+static void scatter_range(GpuTransformCullSystem* s, uint64_t i0, uint64_t i1) {
+    const Batch* b = NULL;
+    uint8_t *wcol = NULL, *lcol = NULL;
+    for (uint64_t i = i0; i < i1;) {
+        const uint32_t slot = s->slot_buf[i];
+        if (!b || slot < b->slot_begin || slot >= b->slot_begin + b->count) {
+            b = &s->batches[s->batch_of[slot]];
+            wcol = (uint8_t*)(b->world_col ? b->world_col : ecs_table_get_column(b->table, b->col_w, 0));
+            lcol = (uint8_t*)(b->local_col ? b->local_col : ecs_table_get_column(b->table, b->col_l, 0));
+        }
+        const uint32_t batch_end = b->slot_begin + b->count;
+        uint64_t j = i + 1;
+        while (j < i1 && s->slot_buf[j] == slot + (uint32_t)(j - i) && s->slot_buf[j] < batch_end) ++j;
+        const size_t r = (size_t)(slot - b->slot_begin) * ROW, bytes = (size_t)(j - i) * ROW;
+        memcpy(wcol + r, s->stage_w + i * ROW, bytes);
+        memcpy(lcol + r, s->stage_l + i * ROW, bytes);
+        i = j;
+    }
+}
+
+typedef struct ScatterJob {
+    GpuTransformCullSystem* s;
+    uint64_t i0, i1;
+} ScatterJob;
+static void* scatter_thread(void* arg) {
+    ScatterJob* j = (ScatterJob*)arg;
+    scatter_range(j->s, j->i0, j->i1);
+    return NULL;
+}
+
+/* The copy back is host-memory work on up to hundreds of thousands of small tables: helpers share it when there is
+ * enough of it (threads live for this one call: the system owns no thread between frames). */
+static void scatter_changed(GpuTransformCullSystem* s, uint64_t m) {
+    uint64_t parts = m / ROWS_PER_THREAD_MIN;
+    if (parts > (uint64_t)s->threads) parts = (uint64_t)s->threads;
+    if (parts < 2) {
+        scatter_range(s, 0, m);
+        return;
+    }
+    pthread_t th[MAX_THREADS];
+    ScatterJob job[MAX_THREADS];
+    int started[MAX_THREADS];
+    for (uint64_t p = 0; p < parts; ++p) {
+        job[p].s = s;
+        job[p].i0 = m * p / parts;
+        job[p].i1 = m * (p + 1) / parts;
+        started[p] = p > 0 && pthread_create(&th[p], NULL, scatter_thread, &job[p]) == 0;
+    }
+    for (uint64_t p = 0; p < parts; ++p)
+        if (!started[p]) scatter_range(s, job[p].i0, job[p].i1); /* part 0, and any part whose thread did not start */
+    for (uint64_t p = 1; p < parts; ++p)
+        if (started[p]) pthread_join(th[p], NULL);
+}
+
+/* Frames ran without readback and now the slot order is about to be rebuilt from the flecs columns (a structural
+ * change): the device holds the newer matrices, and they are addressed by the OLD slot order, whose tables may no
+ * longer exist.  Bring every row home first, entity by entity (one component lookup each: a structural change is
+ * already a slow frame) — except rows whose onSet fired since the last frame: there flecs holds the newer value. */
+static int catch_up_by_entity(GpuTransformCullSystem* s) {
+    const uint64_t n = s->scene_entities;
+    int rc;
+    if ((rc = yh_download_world_aos68(s->scene, s->stage_w, 0, n)) != YH_OK ||
+        (rc = yh_download_local_aos68(s->scene, s->stage_l, 0, n)) != YH_OK)
+        return rc;
+    uint8_t* keep = (uint8_t*)calloc((size_t)(n ? n : 1), 1); /* bit 0: local edited on the host, bit 1: world */
+    if (!keep) return YH_ERR_OOM;
+    for (int k = 0; k < 2; ++k)
+        for (uint64_t i = 0; i < s->n_dirty[k]; ++i) {
+            uint32_t slot;
+            if (map_get(&s->slot_of, s->dirty[k][i], &slot) && slot < n) keep[slot] |= (uint8_t)(1 << k);
+        }
+    for (uint64_t slot = 0; slot < n; ++slot) {
+        const ecs_entity_t e = s->entity_of_slot[slot];
+        if (!ecs_is_alive(s->world, e)) continue;
+        if (!(keep[slot] & 2)) {
+            void* w = (void*)ecs_get_id(s->world, e, s->world_id);
+            if (w) memcpy(w, s->stage_w + slot * ROW, ROW);
+        }
+        if (!(keep[slot] & 1)) {
+            void* l = (void*)ecs_get_id(s->world, e, s->local_id);
+            if (l) memcpy(l, s->stage_l + slot * ROW, ROW);
+        }
+    }
+    free(keep);
+    s->host_stale = 0;
+    return YH_OK;
+}
+
 static void run(ecs_iter_t* it) {
     GpuTransformCullSystem* s = (GpuTransformCullSystem*)it->ctx;
     int rc = YH_OK;
     int rebuilt = 0;
-    if (s->skip_walks && restore_walk(s, it)) {
+    /* Nothing structural happened since the batches were last brought up to date (no observer fired, the query's cache
+     * matched or unmatched no table): they still are the world's tables, row for row.  No iteration, no validation. */
+    const int clean = s->skip_walks && s->trust_observers && !s->structure_dirty && s->scene && s->cached_n && s->batches_live &&
+                      it->query && ecs_query_match_count(it->query) == s->cached_match_count;
+    uint8_t* root_row = NULL;
+    if (clean) {
         ecs_iter_fini(it); /* the iterator is not consumed */
+        s->walks_skipped += 1;
+        s->frames_clean += 1;
     } else {
-        rc = walk(s, it);
-        if (rc != YH_OK || s->n == 0) {
-            s->status = rc;
-            return;
+        s->batches_live = 0;
+        s->structure_dirty = 0; /* (cleared first: what the walk below sees is what the flag stands for) */
+        if (s->skip_walks && restore_walk(s, it)) {
+            ecs_iter_fini(it);
+        } else {
+            rc = walk(s, it);
+            if (rc != YH_OK || s->n == 0) {
+                s->status = rc;
+                return;
+            }
+            rebuilt = !same_as_last_walk(s);
+            s->cached_match_count = it->query ? ecs_query_match_count(it->query) : 0;
         }
-        rebuilt = !same_as_last_walk(s);
-        s->cached_match_count = it->query ? ecs_query_match_count(it->query) : 0;
-    }
-    if (!rebuilt) restore_slots(s);
-    else if ((rc = rebuild(s)) != YH_OK) {
-        s->status = rc;
-        return;
+        if (!rebuilt) restore_slots(s);
+        else {
+            if (s->host_stale && s->scene && (rc = catch_up_by_entity(s)) != YH_OK) {
+                s->status = rc;
+                return;
+            }
+            if ((rc = rebuild(s)) != YH_OK) {
+                s->status = rc;
+                return;
+            }
+        }
+        /* the scene root: every level-0 table must name the same holder of the parent matrix */
+        ecs_entity_t root = 0;
+        for (uint32_t i = 0; i < s->n_batches; ++i) {
+            const Batch* b = &s->batches[i];
+            if (b->level != 0) continue;
+            if (!root) {
+                root = b->src;
+            } else if (root != b->src) {
+                s->status = YH_ERR_UNSUPPORTED; /* more than one root transform: not a reference scene (GameApp.zig:77) */
+                return;
+            }
+        }
+        s->root = root;
+        s->batches_live = 1;
     }
     if (s->bounds_stale && (rc = upload_bounds(s)) != YH_OK) {
         s->status = rc;
         return;
     }
-    /* the scene root: every level-0 table must name the same holder of the parent matrix */
-    uint8_t* root_row = NULL;
-    ecs_entity_t root = 0;
-    for (uint32_t i = 0; i < s->n_batches; ++i) {
-        const Batch* b = &s->batches[i];
-        if (b->level != 0) continue;
-        if (!root) {
-            root = b->src;
-            /* after a walk-free restore the row is looked up: the root's own table may have moved it */
-            root_row = b->up_row ? (uint8_t*)b->up_row : (uint8_t*)ecs_get_id(s->world, root, s->world_id);
-        } else if (root != b->src) {
-            s->status = YH_ERR_UNSUPPORTED; /* more than one root transform: not a reference scene (GameApp.zig:77) */
-            return;
-        }
-    }
+    /* the root's row is looked up every frame: its own table may have moved it */
+    if (s->root) root_row = (uint8_t*)ecs_get_id(s->world, s->root, s->world_id);
     /* matrix and dirty byte exactly as level-0 rows read them through the Up term */
     if (root_row && (rc = yh_upload_root_aos68(s->scene, root_row)) != YH_OK) {
         s->status = rc;
@@ -618,12 +796,25 @@ static void run(ecs_iter_t* it) {
             s->last_up_rows += m;
         }
     }
-    s->n_dirty[0] = s->n_dirty[1] = 0;
     if ((rc = yh_frame(s->scene, s->planes, s->n_frusta, cull_flags)) != YH_OK) {
+        s->n_dirty[0] = s->n_dirty[1] = 0;
         s->status = rc;
         return;
     }
-    if (!s->incremental) {
+    if (s->incremental && !s->readback) {
+        /* A device consumer reads the results where they are (yh_object_data_device, draw lists): nothing comes back.
+         * The rows whose onSet fired had their dirty byte set by the hook; the frame cleared it on the device, so it is
+         * cleared here too — their matrices, and every row the frame recomputed, are now newer on the device. */
+        for (int k = 0; k < 2; ++k)
+            for (uint64_t i = 0; i < s->n_dirty[k]; ++i) {
+                uint32_t slot;
+                if (!map_get(&s->slot_of, s->dirty[k][i], &slot)) continue;
+                const Batch* b = batch_of_slot(s, slot);
+                ((uint8_t*)(k == 0 ? b->local_col : b->world_col))[(size_t)(slot - b->slot_begin) * ROW + 64] = 0;
+            }
+        s->host_stale = 1;
+        s->last_down_rows = 0;
+    } else if (!s->incremental || s->host_stale) {
         if ((rc = yh_download_world_aos68(s->scene, s->stage_w, 0, s->n)) != YH_OK ||
             (rc = yh_download_local_aos68(s->scene, s->stage_l, 0, s->n)) != YH_OK) {
             s->status = rc;
@@ -635,6 +826,7 @@ static void run(ecs_iter_t* it) {
             memcpy(b->local_col, s->stage_l + (size_t)b->slot_begin * ROW, (size_t)b->count * ROW);
         }
         s->last_down_rows = 2 * s->n;
+        s->host_stale = 0;
     } else {
         /* every row the frame recomputed or found dirty, flags cleared; all other rows are as flecs holds them */
         uint64_t m = 0;
@@ -642,20 +834,10 @@ static void run(ecs_iter_t* it) {
             s->status = rc;
             return;
         }
-        const Batch* b = NULL;
-        for (uint64_t i = 0; i < m;) { /* ascending slots: runs of consecutive slots inside a batch go in one copy */
-            const uint32_t slot = s->slot_buf[i];
-            if (!b || slot < b->slot_begin || slot >= b->slot_begin + b->count) b = batch_of_slot(s, slot);
-            const uint32_t batch_end = b->slot_begin + b->count;
-            uint64_t j = i + 1;
-            while (j < m && s->slot_buf[j] == slot + (uint32_t)(j - i) && s->slot_buf[j] < batch_end) ++j;
-            const size_t r = (size_t)(slot - b->slot_begin) * ROW, bytes = (size_t)(j - i) * ROW;
-            memcpy((uint8_t*)b->world_col + r, s->stage_w + i * ROW, bytes);
-            memcpy((uint8_t*)b->local_col + r, s->stage_l + i * ROW, bytes);
-            i = j;
-        }
+        scatter_changed(s, m);
         s->last_down_rows = 2 * m;
     }
+    s->n_dirty[0] = s->n_dirty[1] = 0;
     if (root_row) root_row[64] = 0; /* PostWorldTransform reaches the root too (single-term query) */
     s->status = YH_OK;
 }
@@ -697,6 +879,13 @@ ecs_entity_t GpuTransformCullSystem_registerTo(ecs_world_t* world, ecs_entity_t 
     }
     s->incremental = 1;
     s->skip_walks = 1;
+    s->trust_observers = 1;
+    s->structure_dirty = 1;
+    s->readback = 1;
+    {
+        long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+        s->threads = cpus >= 8 ? 8 : (cpus > 1 ? (int)cpus : 1);
+    }
     for (int k = 0; k < 2; ++k) {
         ecs_observer_desc_t od;
         memset(&od, 0, sizeof od);
@@ -705,6 +894,26 @@ ecs_entity_t GpuTransformCullSystem_registerTo(ecs_world_t* world, ecs_entity_t 
         od.callback = k == 0 ? on_set_local : on_set_world;
         od.ctx = s;
         s->observers[k] = ecs_observer_init(world, &od);
+    }
+    for (int k = 0; k < 2; ++k) { /* any component or tag, any pair: added or removed */
+        ecs_observer_desc_t od;
+        memset(&od, 0, sizeof od);
+        od.query.terms[0].id = k == 0 ? EcsWildcard : ecs_pair(EcsWildcard, EcsWildcard);
+        od.events[0] = EcsOnAdd;
+        od.events[1] = EcsOnRemove;
+        od.callback = note_structure;
+        od.ctx = s;
+        s->observers[2 + k] = ecs_observer_init(world, &od);
+    }
+    for (int k = 0; k < 2; ++k) { /* tables with one of the components created or deleted */
+        ecs_observer_desc_t od;
+        memset(&od, 0, sizeof od);
+        od.query.terms[0].id = k == 0 ? local_transform : world_transform;
+        od.events[0] = EcsOnTableCreate;
+        od.events[1] = EcsOnTableDelete;
+        od.callback = note_table;
+        od.ctx = s;
+        s->observers[4 + k] = ecs_observer_init(world, &od);
     }
     *out_state = s;
     return s->system;
@@ -774,6 +983,40 @@ int GpuTransformCullSystem_setSkipWalks(GpuTransformCullSystem* s, int on) {
     return YH_OK;
 }
 
+int GpuTransformCullSystem_setTrustObservers(GpuTransformCullSystem* s, int on) {
+    if (!s) return YH_ERR_BAD_ARG;
+    s->trust_observers = on != 0;
+    return YH_OK;
+}
+
+int GpuTransformCullSystem_setReadback(GpuTransformCullSystem* s, int on) {
+    if (!s) return YH_ERR_BAD_ARG;
+    s->readback = on != 0;
+    return YH_OK;
+}
+
+int GpuTransformCullSystem_fetchWorld(GpuTransformCullSystem* s, ecs_entity_t entity, float matrix[16]) {
+    if (!s || !matrix || !s->scene) return YH_ERR_BAD_ARG;
+    uint32_t slot;
+    if (!s->slot_of.e || !map_get(&s->slot_of, entity, &slot)) return YH_ERR_BAD_ARG;
+    uint8_t row[ROW];
+    const int rc = yh_download_world_aos68(s->scene, row, slot, 1);
+    if (rc == YH_OK) memcpy(matrix, row, 64);
+    return rc;
+}
+
+int GpuTransformCullSystem_setThreads(GpuTransformCullSystem* s, int n) {
+    if (!s || n < 1) return YH_ERR_BAD_ARG;
+    s->threads = n > MAX_THREADS ? MAX_THREADS : n;
+    return YH_OK;
+}
+
+int GpuTransformCullSystem_structureDirty(const GpuTransformCullSystem* s) { return s ? s->structure_dirty : -1; }
+void GpuTransformCullSystem_clearStructureDirty(GpuTransformCullSystem* s) {
+    if (s) s->structure_dirty = 0;
+}
+uint64_t GpuTransformCullSystem_cleanFrames(const GpuTransformCullSystem* s) { return s ? s->frames_clean : 0; }
+
 void GpuTransformCullSystem_walkStats(const GpuTransformCullSystem* s, uint64_t* walks, uint64_t* skipped) {
     if (walks) *walks = s ? s->walks : 0;
     if (skipped) *skipped = s ? s->walks_skipped : 0;
@@ -797,15 +1040,16 @@ void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     free(s->cached_cols);
     free(s->entity_of_slot);
     free(s->order);
-    free(s->stage_w);
-    free(s->stage_l);
+    free_stage(s);
+    free(s->batch_of);
     free(s->bounds);
     free(s->slot_of.e);
     for (int k = 0; k < 2; ++k) {
         free(s->dirty[k]);
         free(s->stamp[k]);
-        if (s->observers[k] && s->world) ecs_delete(s->world, s->observers[k]);
     }
+    for (unsigned k = 0; k < sizeof s->observers / sizeof s->observers[0]; ++k)
+        if (s->observers[k] && s->world) ecs_delete(s->world, s->observers[k]);
     free(s->slot_buf);
     free(s);
 }

@@ -59,6 +59,29 @@ int GpuTransformCullSystem_setIncremental(GpuTransformCullSystem* s, int on);
  * the last walk's tables are reused.  walkStats: iterations done / frames that skipped it. */
 int GpuTransformCullSystem_setSkipWalks(GpuTransformCullSystem* s, int on);
 void GpuTransformCullSystem_walkStats(const GpuTransformCullSystem* s, uint64_t* walks, uint64_t* skipped);
+/* Structural-change tracking (on by default).  Observers on every id added to or removed from a table that holds one
+ * of the two components (entities created, deleted, re-parented, moved between archetypes by an unrelated component)
+ * and on such tables being created or deleted raise a flag; while it is clear a frame neither iterates the query nor
+ * looks at any table (cleanFrames counts those): its cost is the rows that changed, not the tables that exist
+ * (editor/Editor.zig:590-636 re-parenting, engine/GameApp.zig:204-215 scene load are what raises it in the engine).
+ * Off: every frame compares every cached table's entities with the world's, as round 1 did (20 ms per frame for 300k
+ * tables).  structureDirty / clearStructureDirty: the flag itself (tests). */
+int GpuTransformCullSystem_setTrustObservers(GpuTransformCullSystem* s, int on);
+int GpuTransformCullSystem_structureDirty(const GpuTransformCullSystem* s);
+void GpuTransformCullSystem_clearStructureDirty(GpuTransformCullSystem* s);
+uint64_t GpuTransformCullSystem_cleanFrames(const GpuTransformCullSystem* s);
+/* Readback (on by default): the rows a frame recomputed come back into the flecs columns, so every CPU reader of
+ * WorldTransform.matrix keeps working (RenderApi.zig:1398-1402, SceneWindow.zig:334-351).  Off, for a renderer that
+ * takes matrices and draw records on the device (yh_build_object_data / yh_object_data_device): nothing comes back, a
+ * frame that moved every entity costs what the GPU frame costs; flecs' copies of recomputed rows go stale until
+ * readback is switched on again (the next frame then brings whole columns back).  fetchWorld: one entity's current
+ * world matrix from the device, whatever the mode (the gizmo reads the selected entity's: SceneWindow.zig:334-351). */
+int GpuTransformCullSystem_setReadback(GpuTransformCullSystem* s, int on);
+int GpuTransformCullSystem_fetchWorld(GpuTransformCullSystem* s, ecs_entity_t entity, float matrix[16]);
+/* Helpers that share the copy of changed rows back into the tables when a frame changed many (default: the CPUs
+ * online, at most 8; 1 = the calling thread only).  They live for that one copy; the system owns no thread between
+ * frames. */
+int GpuTransformCullSystem_setThreads(GpuTransformCullSystem* s, int n);
 /* 68-byte rows that crossed PCIe in the last frame, each direction (both components counted). */
 void GpuTransformCullSystem_lastTraffic(const GpuTransformCullSystem* s, uint64_t* rows_up, uint64_t* rows_down);
 
