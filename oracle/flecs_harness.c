@@ -25,7 +25,8 @@
  *            | per frame: u32 n_edits, then {u32 entity (0xFFFFFFFF = root), u32 kind, f32 m[16]} applied before the
  *              frame.  kind 0 / 1: set + modified of the local / world matrix (editor/editors/transform.zig:76-79);
  *              kind 2: delete the entity (children go with it, flecs' ChildOf cleanup);
- *              kind 3: re-parent under entity index bits(m[0]) (ecs.zig:470-477 setParent)
+ *              kind 3: re-parent under entity index bits(m[0]) (ecs.zig:470-477 setParent);
+ *              kinds 4 / 5: change an entity's Mesh / a camera's view_projection (GPU build with YFH_ECS_INPUTS=1, see below)
  * out.bin:   per frame: world rows n x 68 B, local rows n x 68 B (all zero for deleted entities), u64 batches,
  *            u64 rows_seen, u32 up_fields_shared; GPU build + YFH2: then per frustum u32 count, u32 entity_index[count]
  *            (GPU build: batches = slot-order rebuilds so far, rows_seen = entities in the device scene), then
@@ -181,6 +182,70 @@ int main(int argc, char** argv) {
     }
 
 #ifdef USE_GPU_SYSTEM
+    /* YFH_ECS_INPUTS=1: the system reads its cull inputs from the ECS, as in the engine — frusta from Camera entities
+     * (240-byte component, view_projection at offset 176: engine/components/camera.zig:54-66), bounds from the mesh a
+     * Mesh{ref} component points to (engine/components/mesh.zig, engine/meshes.zig:104-110) — instead of setFrusta /
+     * setBounds.  Entity e refers to mesh e % 4 - 1 (none for e % 4 == 0); camera 0 is the benchmark's main camera,
+     * camera 1 its second shadow cascade.  Edit kinds 4 (entity's Mesh := mesh bits(m[0]) - 1) and 5 (camera e's
+     * view_projection := m) exist in this mode only. */
+    typedef struct FakeMesh { /* the layout of engine/meshes.zig Mesh up to its bounds */
+        uint8_t handle[16];
+        uint64_t vertices_count;
+        void* vertices;
+        float bounds[6];
+        uint8_t vertex_buffer[32];
+    } FakeMesh;
+    static FakeMesh fake_meshes[3];
+    const int ecs_inputs = getenv("YFH_ECS_INPUTS") != NULL;
+    ecs_entity_t camera_id = 0, mesh_id = 0, cams[2] = {0, 0};
+    if (ecs_inputs) {
+        ecs_entity_desc_t ed = {0};
+        ed.use_low_id = true;
+        ed.name = "Camera";
+        ecs_component_desc_t cd = {0};
+        cd.entity = ecs_entity_init(w, &ed);
+        cd.type.size = 240;
+        cd.type.alignment = 4;
+        camera_id = ecs_component_init(w, &cd);
+        ecs_entity_desc_t ed2 = {0};
+        ed2.use_low_id = true;
+        ed2.name = "Mesh";
+        ecs_component_desc_t cd2 = {0};
+        cd2.entity = ecs_entity_init(w, &ed2);
+        cd2.type.size = 8;
+        cd2.type.alignment = 8;
+        mesh_id = ecs_component_init(w, &cd2);
+        for (int k = 1; k <= 3; ++k) {
+            FakeMesh* m = &fake_meshes[k - 1];
+            memset(m, 0xAB, sizeof *m);
+            m->vertices_count = 36u * (uint64_t)k;
+            const float b[6] = {-0.5f * k, -0.25f * k - 0.5f, -1.0f, 0.5f * k, 0.25f * k + 0.5f, 1.5f};
+            memcpy(m->bounds, b, sizeof b);
+        }
+        for (uint32_t e = 0; e < n; ++e)
+            if (e % 4) {
+                const FakeMesh* ref = &fake_meshes[e % 4 - 1];
+                ecs_set_id(w, ent[e], mesh_id, sizeof ref, &ref);
+            }
+        uint8_t cam[240];
+        float proj[16], view[16], vp[16];
+        const float eye0[3] = {0.0f, 40.0f, 150.0f}, at[3] = {0.0f, 0.0f, 0.0f}, up[3] = {0.0f, 1.0f, 0.0f};
+        yh_perspective((float)(75.0 * 3.14159265358979323846 / 180.0), 2.0f, 0.1f, 200.0f, proj);
+        proj[5] = proj[5] * -1.0f;
+        yh_look_at(eye0, at, up, view);
+        yh_mat4_mul(proj, view, vp);
+        memset(cam, 0x5A, sizeof cam);
+        memcpy(cam + 176, vp, 64);
+        cams[0] = ecs_new(w);
+        ecs_set_id(w, cams[0], camera_id, sizeof cam, cam);
+        const float eye1[3] = {0.4f * 200.0f, 1.0f * 200.0f, 0.3f * 200.0f};
+        yh_orthographic(-25.0f, 25.0f, -25.0f, 25.0f, 0.0f, 400.0f, proj);
+        yh_look_at(eye1, at, up, view);
+        yh_mat4_mul(proj, view, vp);
+        memcpy(cam + 176, vp, 64);
+        cams[1] = ecs_new(w);
+        ecs_set_id(w, cams[1], camera_id, sizeof cam, cam);
+    }
     yh_ctx* ctx = NULL;
     if (yh_init(0, &ctx) != YH_OK) {
         fprintf(stderr, "flecs_gpu_harness: yh_init: %s\n", yh_last_error(NULL));
@@ -189,7 +254,12 @@ int main(int argc, char** argv) {
     GpuTransformCullSystem* gpu = NULL;
     const ecs_entity_t gsys = GpuTransformCullSystem_registerTo(w, g_local_id, g_world_id, ctx, &gpu);
     if (!gsys) return 3;
-    if (v2) {
+    if (ecs_inputs) {
+        if (GpuTransformCullSystem_setCameraComponent(gpu, camera_id, 176) != YH_OK ||
+            GpuTransformCullSystem_setMeshComponent(gpu, mesh_id, 32, 16) != YH_OK)
+            return 3;
+        n_frusta = 2;
+    } else if (v2) {
         for (uint32_t e = 0; e < n; ++e) GpuTransformCullSystem_setBounds(gpu, ent[e], bounds + 6 * (size_t)e);
         GpuTransformCullSystem_setFrusta(gpu, planes, n_frusta);
     }
@@ -227,6 +297,21 @@ int main(int argc, char** argv) {
                 uint32_t np;
                 memcpy(&np, m, 4);
                 ecs_add_id(w, target, ecs_pair(EcsChildOf, np == 0xFFFFFFFFu ? root : ent[np]));
+                continue;
+            }
+            if (kind == 4 || kind == 5) { /* cull inputs held by the ECS: GPU build with YFH_ECS_INPUTS only */
+#ifdef USE_GPU_SYSTEM
+                if (ecs_inputs && kind == 4) {
+                    uint32_t k;
+                    memcpy(&k, m, 4);
+                    const FakeMesh* ref = &fake_meshes[k - 1];
+                    ecs_set_id(w, target, mesh_id, sizeof ref, &ref);
+                } else if (ecs_inputs) {
+                    uint8_t* cam = (uint8_t*)ecs_ensure_id(w, cams[e], camera_id);
+                    memcpy(cam + 176, m, 64);
+                    ecs_modified_id(w, cams[e], camera_id);
+                }
+#endif
                 continue;
             }
             const ecs_entity_t comp = kind == 0 ? g_local_id : g_world_id;

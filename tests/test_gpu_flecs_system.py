@@ -206,3 +206,63 @@ def test_results_can_stay_on_the_device_until_readback_is_switched_on(oracle, tm
             with np.errstate(all="ignore"):
                 assert np.array_equal(gw["m"], cw["m"], equal_nan=True) and np.array_equal(gl["m"], cl["m"], equal_nan=True)
             assert np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"])
+
+
+def test_the_system_reads_cameras_and_mesh_bounds_from_the_ecs(oracle, tmp_path):
+    """SURVEY 8f N4 / the drop-in's own inputs: no setFrusta, no setBounds.  Two Camera entities (240-byte component,
+    view_projection at offset 176 as in engine/components/camera.zig) give the frusta, a Mesh{ref} component pointing at
+    a meshes.Mesh-shaped struct gives each entity its AABB (three meshes; every fourth entity has none: an empty box);
+    mid-run a camera's matrix and some entities' meshes change.  Visible sets must be the oracle's for those inputs."""
+    from yume_amd import api, synth
+
+    n, levels = 40_000, 6
+    rng = np.random.default_rng(9)
+    lo = oracle.synth_level_offsets(n, levels)
+    par = oracle.synth_parents(lo)
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo[1])))
+    mesh_box = {0: [0, 0, 0, 0, 0, 0]}
+    for k in (1, 2, 3):
+        mesh_box[k] = [-0.5 * k, -0.25 * k - 0.5, -1.0, 0.5 * k, 0.25 * k + 0.5, 1.5]
+    mesh_of = (np.arange(n) % 4).astype(np.int64)
+    cam = [synth.main_camera_planes(), synth.cascade_planes()[1]]
+
+    def arg_u32(v):
+        m = np.zeros(16, np.float32)
+        m.view(np.uint32)[0] = v
+        return m
+
+    new_vp = api.mat4_mul(api.orthographic(-60, 60, -60, 60, 0.0, 400.0), api.look_at([10, 90, 20], [0, 0, 0], [0, 1, 0]))
+    remesh = np.unique(rng.integers(0, n, 500))
+    remesh = remesh[mesh_of[remesh] != 0][:300]  # entities that already have a Mesh: a set, not an add (no row moves)
+    gain = np.unique(rng.integers(0, n, 200))
+    gain = gain[mesh_of[gain] == 0][:40]          # entities that get their first Mesh: an archetype move (structural)
+    frames = [[], [(int(e), 0, oracle.compose(rng.uniform(-5, 5, 3), rng.uniform(-1, 1, 4), [1, 1, 1])) for e in np.unique(rng.integers(0, n, 300))],
+              [(1, 5, new_vp)],
+              [(int(e), 4, arg_u32(int(mesh_of[e]) % 3 + 1)) for e in remesh],
+              [(int(e), 4, arg_u32(2)) for e in gain], []]
+    scene, out_c, out_g = tmp_path / "scene.bin", tmp_path / "cpu.bin", tmp_path / "gpu.bin"
+    write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], np.zeros((1, 24), np.float32), np.zeros((n, 6), np.float32), frames)
+    subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
+    env["YFH_ECS_INPUTS"] = "1"
+    subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
+    cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
+    gpu = read_out(out_g, n, len(frames), 2, oracle.T68, gpu=True)
+    rebuilds_before = 0
+    for fi, ((cw, cl, _, _rows, _), (gw, gl, rebuilds, _g_rows, vis)) in enumerate(zip(cpu, gpu)):
+        for e, kind, m in frames[fi]:
+            if kind == 4:
+                mesh_of[e] = int(m.view(np.uint32)[0])
+            if kind == 5:
+                cam[e] = api.extract_planes(m)
+        with np.errstate(all="ignore"):
+            assert np.array_equal(gw["m"], cw["m"], equal_nan=True) and np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi}"
+        bounds = np.array([mesh_box[int(k)] for k in mesh_of], np.float32)
+        planes = np.stack(cam).astype(np.float32).reshape(2, 24)
+        exp_vis, _ = oracle.cull(np.ascontiguousarray(cw), bounds, planes)
+        for f in range(2):
+            assert np.array_equal(np.sort(vis[f]), np.flatnonzero(exp_vis[f])), f"frame {fi} frustum {f}: visible set"
+            assert vis[f].size > 0
+        # a Mesh set on an entity that has one moves no row (no rebuild); a first Mesh is an archetype move (rebuild)
+        assert rebuilds == rebuilds_before + (1 if fi in (0, 4) else 0), f"frame {fi}: {rebuilds} rebuilds"
+        rebuilds_before = rebuilds

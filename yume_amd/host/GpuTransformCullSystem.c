@@ -29,6 +29,7 @@
 
 #define ROW 68u
 #define MAX_THREADS 32
+#define MESH_TABLE_MAX 65536u /* distinct meshes (+ entities with bounds of their own) a mesh-table scene can hold */
 #define ROWS_PER_THREAD_MIN 8192u /* below this many changed rows per helper a thread costs more than it saves */
 
 typedef struct Batch {
@@ -94,6 +95,16 @@ struct GpuTransformCullSystem {
 
     float planes[YH_MAX_FRUSTA * 24];
     uint32_t n_frusta;
+    uint32_t n_explicit;                      /* frusta handed over with setFrusta: they override the cameras */
+    /* inputs read from the ECS (optional): Camera.view_projection and the AABB of the mesh an entity's Mesh refers to */
+    ecs_entity_t camera_id, mesh_id;
+    uint32_t camera_vp_offset;
+    ecs_query_t* camera_query;
+    ecs_entity_t frustum_camera[YH_MAX_FRUSTA];
+    uint32_t mesh_bounds_offset;
+    int32_t mesh_vertices_offset;
+    uint32_t scene_bounds_kind;               /* bounds kind the device scene was created with */
+    uint32_t n_meshes;                        /* entries of the mesh table of the last upload (entry 0: the empty box) */
 
     /* incremental mode: only rows whose onSet fired go up, only rows the frame touched come back */
     int incremental;
@@ -118,7 +129,7 @@ struct GpuTransformCullSystem {
     uint32_t* stamp[2];      /* per slot: frame in which the row was last queued (duplicates in the dirty lists) */
     uint32_t epoch;
     uint32_t* slot_buf;      /* n entries: slots of a sparse upload / of the changed rows */
-    ecs_entity_t observers[6];
+    ecs_entity_t observers[7];
     uint64_t last_up_rows, last_down_rows;
 
     int status;
@@ -361,7 +372,8 @@ static int rebuild(GpuTransformCullSystem* s) {
     }
     level_offsets[n_levels] = slot;
 
-    if (!s->scene || s->scene_entities != n || s->scene_levels != n_levels) {
+    const uint32_t want_bounds = s->mesh_id ? YH_BOUNDS_MESH_TABLE : YH_BOUNDS_PER_ENTITY;
+    if (!s->scene || s->scene_entities != n || s->scene_levels != n_levels || s->scene_bounds_kind != want_bounds) {
         if (s->scene) yh_scene_destroy(s->scene);
         s->scene = NULL;
         yh_scene_desc d;
@@ -370,7 +382,10 @@ static int rebuild(GpuTransformCullSystem* s) {
         d.n_levels = n_levels;
         d.n_frusta = YH_MAX_FRUSTA;
         d.local_kind = YH_LOCAL_MAT4;
-        d.bounds_kind = YH_BOUNDS_PER_ENTITY;
+        d.bounds_kind = want_bounds;
+        d.max_meshes = want_bounds == YH_BOUNDS_MESH_TABLE ? MESH_TABLE_MAX : 0;
+        s->scene_bounds_kind = want_bounds;
+        s->n_meshes = 0;
         if ((rc = yh_scene_create(s->ctx, &d, &s->scene)) != YH_OK) goto done;
         s->scene_entities = n;
         s->scene_levels = n_levels;
@@ -466,7 +481,106 @@ done:
     return rc;
 }
 
+/* Bounds from the Mesh component (engine/components/mesh.zig: `Mesh{ ref: *meshes.Mesh }`; the AABB is
+ * meshes.Mesh.bounds, engine/meshes.zig:72-95, 104-110): one table entry per distinct mesh, entry 0 the empty box of
+ * entities that have none, a u32 id per entity.  setBounds overrides get entries of their own.  Tables are walked
+ * column-wise: one pointer compare per row, one hash lookup per run of rows that share a mesh. */
+static int upload_bounds_from_meshes(GpuTransformCullSystem* s) {
+    const uint64_t n = s->n;
+    int rc = YH_OK;
+    uint32_t* ids = (uint32_t*)calloc((size_t)(n ? n : 1), sizeof(uint32_t));
+    float* table = (float*)calloc((size_t)MESH_TABLE_MAX * 6, sizeof(float));
+    uint32_t* vcount = (uint32_t*)calloc((size_t)MESH_TABLE_MAX, sizeof(uint32_t));
+    Map index_of = {0};
+    uint32_t n_meshes = 1; /* entry 0: no mesh = an empty box at the origin */
+    if (!ids || !table || !vcount || map_init(&index_of, 4096) != 0) {
+        rc = YH_ERR_OOM;
+        goto done;
+    }
+    for (uint32_t bi = 0; bi < s->n_batches && rc == YH_OK; ++bi) {
+        const Batch* b = &s->batches[bi];
+        if (!b->table) continue;
+        const int32_t col = ecs_table_get_column_index(s->world, b->table, s->mesh_id);
+        if (col < 0) continue;
+        const uint8_t* const* refs = (const uint8_t* const*)ecs_table_get_column(b->table, col, 0);
+        const uint8_t* prev = NULL;
+        uint32_t prev_id = 0;
+        for (uint32_t r = 0; r < b->count; ++r) {
+            const uint8_t* mesh = refs[r];
+            if (!mesh) continue;
+            if (mesh != prev) {
+                uint32_t id;
+                if (!map_get(&index_of, (ecs_entity_t)(uintptr_t)mesh, &id)) {
+                    if (n_meshes == MESH_TABLE_MAX || index_of.cap < (uint64_t)n_meshes * 2 + 2) { /* (map sized for 4096 x 2) */
+                        if (n_meshes == MESH_TABLE_MAX) {
+                            rc = YH_ERR_CAPACITY;
+                            break;
+                        }
+                        Map bigger = {0};
+                        if (map_init(&bigger, index_of.cap) != 0) {
+                            rc = YH_ERR_OOM;
+                            break;
+                        }
+                        for (uint64_t q = 0; q < index_of.cap; ++q)
+                            if (index_of.e[q].key) map_put(&bigger, index_of.e[q].key, index_of.e[q].value);
+                        free(index_of.e);
+                        index_of = bigger;
+                    }
+                    id = n_meshes++;
+                    memcpy(table + 6 * (size_t)id, mesh + s->mesh_bounds_offset, 24); /* BoundingBox{mins, maxs} */
+                    if (s->mesh_vertices_offset >= 0) {
+                        uint64_t vc;
+                        memcpy(&vc, mesh + s->mesh_vertices_offset, 8); /* vertices_count: usize */
+                        vcount[id] = vc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vc;
+                    }
+                    map_put(&index_of, (ecs_entity_t)(uintptr_t)mesh, id);
+                }
+                prev = mesh;
+                prev_id = id;
+            }
+            ids[b->slot_begin + r] = prev_id;
+        }
+    }
+    if (rc == YH_OK && s->bounds_n) /* per-entity overrides */
+        for (uint64_t e = 0; e < n && rc == YH_OK; ++e) {
+            const BoundsEntry* o = bounds_find(s, s->entity_of_slot[e]);
+            if (!o) continue;
+            if (n_meshes == MESH_TABLE_MAX) {
+                rc = YH_ERR_CAPACITY;
+                break;
+            }
+            memcpy(table + 6 * (size_t)n_meshes, o->mm, 24);
+            ids[e] = n_meshes++;
+        }
+    if (rc != YH_OK) goto done;
+    /* ids first while they are all 0 .. old table, then the table, then the ids (the table may not shrink below an
+     * id in use): zero ids are valid for every table */
+    {
+        uint32_t* zero = (uint32_t*)calloc((size_t)(n ? n : 1), sizeof(uint32_t));
+        if (!zero) {
+            rc = YH_ERR_OOM;
+            goto done;
+        }
+        rc = s->n_meshes ? yh_upload_mesh_ids(s->scene, zero, 0, n) : YH_OK;
+        free(zero);
+    }
+    if (rc == YH_OK) rc = yh_upload_mesh_aabbs(s->scene, table, n_meshes);
+    if (rc == YH_OK) rc = yh_upload_mesh_ids(s->scene, ids, 0, n);
+    if (rc == YH_OK && s->mesh_vertices_offset >= 0) rc = yh_upload_vertex_counts(s->scene, vcount, n_meshes);
+    if (rc == YH_OK) {
+        s->n_meshes = n_meshes;
+        s->bounds_stale = 0;
+    }
+done:
+    free(ids);
+    free(table);
+    free(vcount);
+    free(index_of.e);
+    return rc;
+}
+
 static int upload_bounds(GpuTransformCullSystem* s) {
+    if (s->scene_bounds_kind == YH_BOUNDS_MESH_TABLE) return upload_bounds_from_meshes(s);
     const uint64_t n = s->n;
     float* planes = (float*)calloc((size_t)n * 6, sizeof(float)); /* no bounds = empty box at the origin */
     if (!planes) return YH_ERR_OOM;
@@ -757,6 +871,25 @@ static void run(ecs_iter_t* it) {
         s->status = rc;
         return;
     }
+    /* frusta: the ones handed over with setFrusta, else one per Camera entity, from Camera.view_projection as the
+     * engine last updated it (components/camera.zig:300-302; GameWindow.zig:154-178 draws once per such entity) */
+    if (!s->n_explicit && s->camera_query) {
+        uint32_t nf = 0;
+        ecs_iter_t cit = ecs_query_iter(s->world, s->camera_query);
+        while (ecs_query_next(&cit)) {
+            const int32_t col = cit.table ? ecs_table_get_column_index(s->world, cit.table, s->camera_id) : -1;
+            if (col < 0) continue;
+            const size_t size = ecs_table_get_column_size(cit.table, col);
+            const uint8_t* cams = (const uint8_t*)ecs_table_get_column(cit.table, col, cit.offset);
+            for (int32_t r = 0; r < cit.count && nf < YH_MAX_FRUSTA; ++r) {
+                float vp[16];
+                memcpy(vp, cams + (size_t)r * size + s->camera_vp_offset, 64);
+                yh_extract_planes(vp, s->planes + 24 * nf);
+                s->frustum_camera[nf++] = cit.entities[r];
+            }
+        }
+        s->n_frusta = nf;
+    }
     const uint32_t cull_flags = s->n_frusta ? 0u : YH_FRAME_NO_CULL;
     if (!s->incremental || rebuilt) {
         /* whole columns up; in plain mode whole columns down again */
@@ -942,6 +1075,8 @@ int GpuTransformCullSystem_setFrusta(GpuTransformCullSystem* s, const float* pla
     if (!s || n_frusta > YH_MAX_FRUSTA || (n_frusta && !planes)) return YH_ERR_BAD_ARG;
     if (n_frusta) memcpy(s->planes, planes, sizeof(float) * 24u * n_frusta);
     s->n_frusta = n_frusta;
+    s->n_explicit = n_frusta; /* 0: back to the Camera entities, if a camera component is known */
+    memset(s->frustum_camera, 0, sizeof s->frustum_camera);
     return YH_OK;
 }
 
@@ -989,6 +1124,59 @@ int GpuTransformCullSystem_setTrustObservers(GpuTransformCullSystem* s, int on) 
     return YH_OK;
 }
 
+static void note_mesh_set(ecs_iter_t* it) { ((GpuTransformCullSystem*)it->ctx)->bounds_stale = 1; }
+
+int GpuTransformCullSystem_setCameraComponent(GpuTransformCullSystem* s, ecs_entity_t camera, uint32_t view_projection_offset) {
+    if (!s || !camera) return YH_ERR_BAD_ARG;
+    const ecs_type_info_t* ti = ecs_get_type_info(s->world, camera);
+    if (!ti || (uint64_t)view_projection_offset + 64 > (uint64_t)ti->size) return YH_ERR_BAD_ARG;
+    if (s->camera_query) ecs_query_fini(s->camera_query);
+    ecs_query_desc_t qd;
+    memset(&qd, 0, sizeof qd);
+    qd.terms[0].id = camera;
+    qd.terms[0].inout = EcsIn;
+    qd.cache_kind = EcsQueryCacheAuto;
+    s->camera_query = ecs_query_init(s->world, &qd);
+    if (!s->camera_query) return YH_ERR_BAD_ARG;
+    s->camera_id = camera;
+    s->camera_vp_offset = view_projection_offset;
+    return YH_OK;
+}
+
+int GpuTransformCullSystem_setMeshComponent(GpuTransformCullSystem* s, ecs_entity_t mesh, uint32_t bounds_offset,
+                                            int32_t vertices_count_offset) {
+    if (!s || !mesh) return YH_ERR_BAD_ARG;
+    const ecs_type_info_t* ti = ecs_get_type_info(s->world, mesh);
+    if (!ti || ti->size != (ecs_size_t)sizeof(void*)) return YH_ERR_BAD_ARG; /* Mesh{ ref: *meshes.Mesh } */
+    s->mesh_id = mesh;
+    s->mesh_bounds_offset = bounds_offset;
+    s->mesh_vertices_offset = vertices_count_offset;
+    if (!s->observers[6]) { /* a Mesh set on an entity that already has one moves no row: only the bounds go stale */
+        ecs_observer_desc_t od;
+        memset(&od, 0, sizeof od);
+        od.query.terms[0].id = mesh;
+        od.events[0] = EcsOnSet;
+        od.callback = note_mesh_set;
+        od.ctx = s;
+        s->observers[6] = ecs_observer_init(s->world, &od);
+    }
+    s->cached_n = 0; /* the device scene changes its bounds kind: rebuild */
+    s->structure_dirty = 1;
+    return YH_OK;
+}
+
+int GpuTransformCullSystem_invalidateBounds(GpuTransformCullSystem* s) {
+    if (!s) return YH_ERR_BAD_ARG;
+    s->bounds_stale = 1;
+    return YH_OK;
+}
+
+ecs_entity_t GpuTransformCullSystem_frustumCamera(const GpuTransformCullSystem* s, uint32_t frustum) {
+    return (s && frustum < s->n_frusta) ? s->frustum_camera[frustum] : 0;
+}
+uint32_t GpuTransformCullSystem_frusta(const GpuTransformCullSystem* s) { return s ? s->n_frusta : 0; }
+yh_scene* GpuTransformCullSystem_scene(GpuTransformCullSystem* s) { return s ? s->scene : NULL; }
+
 int GpuTransformCullSystem_setReadback(GpuTransformCullSystem* s, int on) {
     if (!s) return YH_ERR_BAD_ARG;
     s->readback = on != 0;
@@ -1030,6 +1218,7 @@ void GpuTransformCullSystem_lastTraffic(const GpuTransformCullSystem* s, uint64_
 void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     if (!s) return;
     if (s->scene) yh_scene_destroy(s->scene);
+    if (s->camera_query) ecs_query_fini(s->camera_query);
     free(s->batches);
     free(s->walk_entities);
     free(s->cached_entities);

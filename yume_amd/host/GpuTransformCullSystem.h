@@ -42,6 +42,28 @@ int GpuTransformCullSystem_setBounds(GpuTransformCullSystem* s, ecs_entity_t ent
 /* Frusta of the next frames: n x 24 floats (yh_extract_planes of Camera.view_projection, camera.zig:300-302). */
 int GpuTransformCullSystem_setFrusta(GpuTransformCullSystem* s, const float* planes, uint32_t n_frusta);
 
+/* Inputs read from the ECS itself (optional).
+ * setCameraComponent: the id of the engine's Camera component and @offsetOf(Camera, "view_projection")
+ * (engine/components/camera.zig:54-66: 176 in the reference's layout).  Every frame culls against one frustum per
+ * Camera entity (query order, at most YH_MAX_FRUSTA), planes taken from its view_projection as the engine last updated
+ * it (camera.zig:300-302; the reference does that at draw time, GameWindow.zig:154-178, so a camera that moved is seen
+ * one frame late unless the engine updates matrices before world.progress).  frustumCamera(f): the entity behind
+ * frustum f.  Frusta handed over with setFrusta take precedence; setFrusta(NULL, 0) returns to the cameras.
+ * setMeshComponent: the id of the Mesh component (`Mesh{ ref: *meshes.Mesh }`, engine/components/mesh.zig), and
+ * @offsetOf(meshes.Mesh, "bounds") / @offsetOf(meshes.Mesh, "vertices_count") inside what `ref` points to
+ * (engine/meshes.zig:104-110; vertices_count_offset < 0: none).  The device scene then holds one AABB per distinct
+ * mesh and a mesh id per entity (entities without a Mesh: an empty box at the origin), so per-mesh draw buckets
+ * (yh_build_mesh_buckets on GpuTransformCullSystem_scene) work on the system's scene; bounds follow Mesh
+ * sets and structural changes by themselves, invalidateBounds re-reads them when a mesh asset itself was reloaded.
+ * setBounds stays as a per-entity override.  At most 65535 distinct meshes + overrides (YH_ERR_CAPACITY beyond). */
+int GpuTransformCullSystem_setCameraComponent(GpuTransformCullSystem* s, ecs_entity_t camera, uint32_t view_projection_offset);
+int GpuTransformCullSystem_setMeshComponent(GpuTransformCullSystem* s, ecs_entity_t mesh, uint32_t bounds_offset,
+                                            int32_t vertices_count_offset);
+int GpuTransformCullSystem_invalidateBounds(GpuTransformCullSystem* s);
+ecs_entity_t GpuTransformCullSystem_frustumCamera(const GpuTransformCullSystem* s, uint32_t frustum);
+uint32_t GpuTransformCullSystem_frusta(const GpuTransformCullSystem* s);
+yh_scene* GpuTransformCullSystem_scene(GpuTransformCullSystem* s);
+
 /* Visible entities of the last frame for one frustum, ascending slot order.  Returns the count; writes at most cap. */
 uint64_t GpuTransformCullSystem_visible(GpuTransformCullSystem* s, uint32_t frustum, ecs_entity_t* out, uint64_t cap);
 
