@@ -159,3 +159,51 @@ def test_bench_parses_and_names_the_largest_single_gpu_configuration_by_default(
     lo = np.array([0, 1000], np.uint32)
     own, lists = bench.algorithmic_bytes(bench.WORKLOADS["cfg3"], lo, None, 0, 1000, 5, 1234.0)
     assert own == 1000 * (40 + 64 + 24) + 5 * (1000 / 8 + 1000 / 64) and lists == 4 * 1234.0
+
+
+def test_zig_binding_is_generated_from_the_header_and_complete():
+    """zig/engine/hip/yume_hip.zig binds EVERY symbol of include/yume_hip.h (one `pub extern fn` each, same number of
+    parameters) and is exactly what tools/gen_zig_ffi.py makes of the header today."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_zig_ffi", os.path.join(ROOT, "tools", "gen_zig_ffi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    zig = open(os.path.join(ROOT, "zig", "engine", "hip", "yume_hip.zig")).read()
+    assert zig == gen.generate(), "run `python tools/gen_zig_ffi.py`: the committed Zig binding is not what the header generates"
+    bound = dict(re.findall(r"pub extern fn (yh_[a-z0-9_]+)\((.*?)\) [^;]+;", zig))
+    assert sorted(bound) == declared_functions()
+    for ret, name, args in gen.prototypes():
+        n_zig = 0 if not bound[name].strip() else len(re.findall(r"[A-Za-z_][A-Za-z0-9_]*: ", bound[name]))
+        assert n_zig == len(args), f"{name}: {len(args)} C parameters, {n_zig} in Zig"
+
+
+def test_zig_system_binds_every_function_of_the_c_system_header():
+    """zig/engine/systems/GpuTransformCullSystem.zig declares every GpuTransformCullSystem_* function of the C header
+    it wraps (test hooks aside), and keeps the reference's registerTo signature (TransformSyncSystem.zig:12)."""
+    h = open(os.path.join(ROOT, "yume_amd", "host", "GpuTransformCullSystem.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    declared = set(re.findall(r"\b(GpuTransformCullSystem_[A-Za-z]+)\s*\(", h))
+    z = open(os.path.join(ROOT, "zig", "engine", "systems", "GpuTransformCullSystem.zig")).read()
+    bound = set(re.findall(r"extern fn (GpuTransformCullSystem_[A-Za-z]+)\(", z))
+    hooks = {"GpuTransformCullSystem_structureDirty", "GpuTransformCullSystem_clearStructureDirty"}
+    assert declared - hooks == bound, (sorted(declared - hooks - bound), sorted(bound - declared))
+    assert "pub fn registerTo(world: ecs.World) ecs.Entity {" in z
+
+
+def test_integration_patch_applies_to_the_reference_tree(tmp_path):
+    """zig/yume.patch (build.zig, engine/ecs.zig `systems` export, the editor's call site) applies cleanly to the
+    reference as it is here.  Skips where the reference is absent (GPU box)."""
+    import shutil
+
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "build.zig")):
+        pytest.skip("no reference tree")
+    for rel in ("build.zig", "engine/ecs.zig", "editor/Editor.zig"):
+        os.makedirs(os.path.dirname(tmp_path / rel), exist_ok=True)
+        shutil.copy(os.path.join(ref, rel), tmp_path / rel)
+    subprocess.check_call(["patch", "-p1", "-s", "-i", os.path.join(ROOT, "zig", "yume.patch")], cwd=tmp_path)
+    assert "GpuTransformCullSystem.c" in open(tmp_path / "build.zig").read()
+    assert "GpuTransformCullSystem = @import" in open(tmp_path / "engine/ecs.zig").read()
+    ed = open(tmp_path / "editor/Editor.zig").read()
+    assert "GpuTransformCullSystem.registerTo(ctx.world)" in ed and "PostTransformSystem.registerTo" not in ed
