@@ -267,6 +267,10 @@ int yh_scene_get_group_kernel_names(yh_scene* s, char* buf, uint64_t cap, uint32
  * n_groups = 0 returns to the planner.                                                                   */
 int yh_scene_set_grouping(yh_scene* s, uint32_t max_group_levels);
 int yh_scene_set_plan(yh_scene* s, uint32_t n_groups, const uint32_t* last_level);
+/* One-level launches of a TRS scene (a group of exactly one level > 0) stage the workgroup's span of parent rows in
+ * LDS instead of gathering them through L1/L2.  Same results; off by default (measured slower or equal on the
+ * benchmark trees, profiles/r02/ab_lds_parents.txt) — kept selectable for hierarchies with many children per parent. */
+int yh_scene_set_lds_parents(yh_scene* s, int enable);
 
 /* ---- frustum helpers (host, scalar; same arithmetic as the kernels' inputs expect) --------------------- */
 /* Gribb-Hartmann planes from a column-major view-projection matrix (camera.zig:300-302; depth 0..1 as

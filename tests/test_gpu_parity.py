@@ -698,3 +698,39 @@ def test_planes_that_share_normals_are_culled_exactly_like_planes_tested_one_by_
                 assert bcounts[f] == np.count_nonzero(bnd[f]), (name, f, "boundary count")
             if name == "touching planes":
                 assert bcounts[0] > 0, "the touching set is meant to produce boundary cases"
+
+
+@pytest.mark.parametrize("n,levels", [(4096, 8), (300_000, 6), (1_000_000, 8)])
+def test_lds_staged_parents_give_identical_results(ctx, oracle, n, levels):
+    """The one-level kernel with its parents staged in LDS (yh_scene_set_lds_parents: the variant north_star names)
+    against the oracle and against the default L1/L2 gather, one level per launch; also with UNSORTED siblings and with
+    parents whose children span more rows than the staging area holds (the kernel's fallback)."""
+    from yume_amd import Scene
+
+    lo = oracle.synth_level_offsets(n, levels)
+    par = oracle.synth_parents(lo)
+    rng = np.random.default_rng(3)
+    shuffled = par.copy()
+    for k in range(1, levels):  # the same multiset of parents per level, in random order
+        seg = slice(int(lo[k]), int(lo[k + 1]))
+        shuffled[seg] = rng.permutation(shuffled[seg])
+    trs = oracle.synth_trs(n, int(lo[1]))
+    bounds = oracle.synth_aabb(n)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    for parents in (par, shuffled):
+        exp = oracle.frame_trs(trs, parents, lo, n_threads=8)
+        vis, _ = oracle.cull(exp, bounds, planes, n_threads=8)
+        with Scene(ctx, n, n_levels=levels, n_frusta=1) as s:
+            s.upload_hierarchy(parents, lo)
+            s.upload_trs(trs)
+            s.upload_aabb(np.ascontiguousarray(bounds[:, :3].T), np.ascontiguousarray(bounds[:, 3:].T))
+            s.set_grouping(1)
+            s.set_lds_parents(True)
+            s.frame(planes)
+            assert any("k_frame_trs_lds" in k for k in s.group_kernel_names())
+            assert_same_values(s.world_soa(), exp["m"].T, "world, parents staged in LDS")
+            assert np.array_equal(s.draw_list(0), np.flatnonzero(vis[0]).astype(np.uint32))
+            s.set_lds_parents(False)
+            s.frame(planes)
+            assert not any("k_frame_trs_lds" in k for k in s.group_kernel_names())
+            assert_same_values(s.world_soa(), exp["m"].T, "world, parents gathered")

@@ -128,6 +128,7 @@ SIGNATURES = {
     "yh_get_gathered_counts": (_int, [_vp, _vp]),
     "yh_decompose": (_int, [_vp, _int, _vp, _vp, _u64, _u64]),
     "yh_scene_set_plan": (_int, [_vp, _u32, _vp]),
+    "yh_scene_set_lds_parents": (_int, [_vp, _int]),
     "yh_scene_get_groups": (_int, [_vp, _vp, _u32, C.POINTER(_u32)]),
     "yh_scene_get_group_timings": (_int, [_vp, _vp, _vp, _u32]),
     "yh_scene_get_group_kernel_names": (_int, [_vp, _vp, _u64, C.POINTER(_u32)]),

@@ -182,6 +182,10 @@ class Scene:
     def set_grouping(self, max_group_levels):
         self._ck(L.lib().yh_scene_set_grouping(self._h, int(max_group_levels)))
 
+    def set_lds_parents(self, enable=True):
+        """One-level launches stage their parents in LDS (same results; an A/B variant)."""
+        self._ck(L.lib().yh_scene_set_lds_parents(self._h, int(bool(enable))))
+
     def set_plan(self, last_levels=()):
         """Explicit launch plan: group i ends at level last_levels[i]; empty = back to the planner."""
         ll = np.ascontiguousarray(last_levels, np.uint32)

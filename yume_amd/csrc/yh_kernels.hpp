@@ -420,6 +420,62 @@ __device__ __forceinline__ void frame_chain_tile(const FrameArgs& a, const uint3
     }
 }
 
+// The one-level kernel with the parents STAGED IN LDS (what north_star names; kept as a selectable variant and an A/B,
+// DESIGN.md 4): siblings are sorted by parent, so the 256 children of a workgroup read parents pidx(first) ..
+// pidx(last); when that span fits (<= YH_LDS_PARENTS rows) the workgroup loads it once, coalesced, plane by plane, and
+// every lane takes its parent's 16 floats from LDS (row q of the staging area holds plane q of the span: lanes with
+// neighbouring parents hit neighbouring banks, lanes with the same parent broadcast) instead of through L1/L2.
+#define YH_LDS_PARENTS 192
+template <int BOUNDS, bool BIG>
+__global__ __launch_bounds__(YH_BLOCK) void k_frame_trs_lds(const FrameArgs a) {
+    __shared__ float s_par[16 * YH_LDS_PARENTS];
+    __shared__ uint32_t s_span[8];
+    const uint32_t tile = xcd_tile(a, blockIdx.x);
+    if (tile >= a.n_tiles) return;  // whole workgroup
+    const uint32_t tid = threadIdx.x;
+    const uint64_t e64 = (uint64_t)(a.begin & ~63u) + (uint64_t)tile * YH_BLOCK + tid;
+    const bool wave_on = e64 - (tid & 63u) < a.end;  // wave-uniform; no early exit: every wave meets the barriers
+    const bool valid = e64 >= a.begin && e64 < a.end;
+    const uint32_t e = e64 < a.begin ? a.begin : (e64 < a.end ? (uint32_t)e64 : a.end - 1u);
+    TrsInputs<BOUNDS> in;
+    load_inputs<BOUNDS, true, BIG>(a, e, in);
+    // span of parents the workgroup reads (a true min / max: yh_upload_hierarchy does not insist on sorted siblings)
+    uint32_t lo = in.pidx, hi = in.pidx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor(lo, o));
+        hi = max(hi, (uint32_t)__shfl_xor(hi, o));
+    }
+    if ((tid & 63u) == 0) {
+        s_span[tid >> 6] = lo;
+        s_span[4 + (tid >> 6)] = hi;
+    }
+    __syncthreads();
+    const uint32_t pmin = min(min(s_span[0], s_span[1]), min(s_span[2], s_span[3]));
+    const uint32_t span = max(max(s_span[4], s_span[5]), max(s_span[6], s_span[7])) - pmin + 1u;
+    M4 w;
+    if (span <= YH_LDS_PARENTS) {  // workgroup-uniform
+        for (uint32_t i = tid; i < span * 16u; i += YH_BLOCK) {
+            const uint32_t q = i / span, p = pmin + (i - q * span);
+            s_par[q * YH_LDS_PARENTS + (p - pmin)] = lde(a.world, eoff<16>(p), (int)q);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w.v[q] = s_par[q * YH_LDS_PARENTS + (in.pidx - pmin)];
+    } else {
+        load_row<16>(a.world, in.pidx, w.v);
+    }
+    if (!wave_on) return;
+    w = m4_mul(w, m4_compose(in.t[0], in.t[1], in.t[2], in.t[3], in.t[4], in.t[5], in.t[6], in.t[7], in.t[8], in.t[9]));
+    if (valid) store_row<16>(a.world, e, w.v);
+    if (BOUNDS != 0) {
+        uint32_t vmask = 0, bmask = 0;
+        cull_entity<BOUNDS>(a, w, in.b, in.mesh, vmask, bmask);
+        if (!valid) vmask = bmask = 0;
+        publish_visible(a, (uint32_t)(e64 >> 6), e64 - (tid & 63u) < a.begin, vmask, bmask);
+    }
+}
+
 template <int BOUNDS, bool HAS_BASE>
 __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs(const FrameArgs a) {
     const uint32_t tile = xcd_tile(a, blockIdx.x);

@@ -111,6 +111,8 @@ struct yh_scene {
     bool frame_pending = false;
     uint32_t last_n_frusta = 0;
     uint32_t n_meshes = 0;
+    uint64_t big_tree = YH_BIG_TREE, big_flat = YH_BIG_FLAT;  // entities from which read-once inputs are streamed (A/B: env of the same names)
+    bool lds_parents = false;  // one-level launches stage their parents in LDS (yh_scene_set_lds_parents / YH_LDS_PARENTS=1)
     bool use_cull_plan = true;  // group planes by normal when some share one (YH_NO_CULL_PLAN=1 in the environment: A/B runs)
     uint32_t max_mesh_id = 0;  // largest id ever uploaded (ids start out as 0): the table may not shrink below it
     float root[16];
@@ -433,6 +435,9 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
         return code;
     }
     if (const char* v = getenv("YH_NO_CULL_PLAN")) s->use_cull_plan = !(v[0] == '1');
+    if (const char* v = getenv("YH_LDS_PARENTS")) s->lds_parents = v[0] == '1';
+    if (const char* v = getenv("YH_BIG_TREE")) s->big_tree = strtoull(v, nullptr, 10);
+    if (const char* v = getenv("YH_BIG_FLAT")) s->big_flat = strtoull(v, nullptr, 10);
     ctx->scenes.push_back(s);
     *out = s;
     return YH_OK;
@@ -521,6 +526,12 @@ extern "C" int yh_scene_set_grouping(yh_scene* s, uint32_t max_group_levels) {
     s->max_group_levels = max_group_levels;
     s->explicit_plan.clear();
     if (s->have_hierarchy) return plan_groups(s);
+    return YH_OK;
+}
+
+extern "C" int yh_scene_set_lds_parents(yh_scene* s, int enable) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_scene_set_lds_parents: scene is NULL");
+    s->lds_parents = enable != 0;
     return YH_OK;
 }
 
@@ -951,6 +962,13 @@ static inline const char* tf(bool b) { return b ? "true" : "false"; }
 static inline int chain_g(int G) { return G <= 2 ? 2 : G <= 3 ? 3 : G <= 4 ? 4 : G <= 6 ? 6 : 8; }
 
 template <int BOUNDS>
+static std::string launch_trs_lds(dim3 grid, hipStream_t st, LaunchEvents ev, const FrameArgs& a, bool big) {
+    if (big) YH_LAUNCH((k_frame_trs_lds<BOUNDS, true>), grid, st, ev, a);
+    else YH_LAUNCH((k_frame_trs_lds<BOUNDS, false>), grid, st, ev, a);
+    return kname("void k_frame_trs_lds<%d, %s>(FrameArgs)", BOUNDS, tf(big));
+}
+
+template <int BOUNDS>
 static std::string launch_trs(bool has_base, dim3 grid, hipStream_t st, LaunchEvents ev, const FrameArgs& a, bool big) {
     if (big && has_base) YH_LAUNCH((k_frame_trs_big<BOUNDS, true>), grid, st, ev, a);
     else if (big) YH_LAUNCH((k_frame_trs_big<BOUNDS, false>), grid, st, ev, a);
@@ -1252,14 +1270,18 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
                     a.lvl_begin[j] = (g.lo + 1 + j <= g.hi) ? s->level_offsets[g.lo + 1 + j] : 0xFFFFFFFFu;
                 const dim3 grid = grid_for(a);
                 const int G = (int)(g.hi - g.lo + 1);
-                const bool big = s->n >= (uint64_t)YH_BIG_TREE;
+                const bool big = s->n >= s->big_tree;
                 if (bounds == 0) kn = launch_chain<0>(G, has_base, grid, st, ev, a, big);
                 else if (bounds == 1) kn = launch_chain<1>(G, has_base, grid, st, ev, a, big);
                 else kn = launch_chain<2>(G, has_base, grid, st, ev, a, big);
             } else {
                 const dim3 grid = grid_for(a, s->desc.n_levels == 1);
-                const bool big = s->n >= (s->desc.n_levels == 1 ? (uint64_t)YH_BIG_FLAT : (uint64_t)YH_BIG_TREE);
-                if (bounds == 0) kn = launch_trs<0>(has_base, grid, st, ev, a, big);
+                const bool big = s->n >= (s->desc.n_levels == 1 ? s->big_flat : s->big_tree);
+                if (has_base && s->lds_parents) {  // parents staged in LDS (A/B variant, yh_scene_set_lds_parents)
+                    if (bounds == 0) kn = launch_trs_lds<0>(grid, st, ev, a, big);
+                    else if (bounds == 1) kn = launch_trs_lds<1>(grid, st, ev, a, big);
+                    else kn = launch_trs_lds<2>(grid, st, ev, a, big);
+                } else if (bounds == 0) kn = launch_trs<0>(has_base, grid, st, ev, a, big);
                 else if (bounds == 1) kn = launch_trs<1>(has_base, grid, st, ev, a, big);
                 else kn = launch_trs<2>(has_base, grid, st, ev, a, big);
             }
@@ -1285,7 +1307,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
                 else if (bounds == 1) kn = launch_chain_mat4<1>(G, has_base, grid, st, a, s->root_dirty);
                 else kn = launch_chain_mat4<2>(G, has_base, grid, st, a, s->root_dirty);
             } else {
-                const bool big = s->n >= (uint64_t)YH_BIG_TREE;  // 12.5M columns, all dirty: 452 -> 417 us with streamed locals and bounds
+                const bool big = s->n >= s->big_tree;  // 12.5M columns, all dirty: 452 -> 417 us with streamed locals and bounds
                 if (bounds == 0) kn = launch_mat4<0>(has_base, big, grid, st, a, s->root_dirty);
                 else if (bounds == 1) kn = launch_mat4<1>(has_base, big, grid, st, a, s->root_dirty);
                 else kn = launch_mat4<2>(has_base, big, grid, st, a, s->root_dirty);
