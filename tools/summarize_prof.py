@@ -5,21 +5,22 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out_dir = os.path.join("profiles", rnd)
 os.makedirs(out_dir, exist_ok=True)
 lines = [f"# rocprofv3 evidence, round {rnd[1:]}", "",
-         "Collected on one MI355X (gfx950) with `tools/profile.sh <workload>`: one `--kernel-trace --stats` run of",
-         "`bench.py --workload <w> --steps 200 --warmup 20`, then separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs",
+         "Collected on one MI355X (gfx950) with `tools/profile_r02.sh`: `default` is the driver's own command (`python3 bench.py`,",
+         "CPU leg off) under `--kernel-trace --stats`; per workload `tools/profile.sh <workload>` = one `--kernel-trace --stats` run of",
+         "`bench.py --workload <w> --no-sub --steps 400 --warmup 20`, then separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs",
          "(20 steps).  Counter units are KiB per dispatch.  gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE",
          "reports exactly 1/2 of coalesced streaming reads — calibrated here on the flat 16M kernel, whose compulsory",
          "reads are 64 B x 16,777,216 = 1,048,576 KiB against FETCH_SIZE = 524,327 KiB (ratio 0.50003); WRITE_SIZE is",
          "exact (k_synth writes 64 B/entity: 1,048,576 KiB expected and reported).  traffic = 2 x FETCH_SIZE + WRITE_SIZE.", ""]
 for d in sorted(glob.glob("gpurun_out/prof_*")):
     w = os.path.basename(d)[5:]
-    stats = glob.glob(f"{d}/trace/vm/*_kernel_stats.csv")
+    stats = sorted(glob.glob(f"{d}/trace/vm/*_kernel_stats.csv"), key=os.path.getmtime, reverse=True)  # newest run first
     if not stats:
         continue
     shutil.copy(stats[0], os.path.join(out_dir, f"{w}_kernel_stats.csv"))
     pmc = {}
     for kind in ("fetch", "write"):
-        f = glob.glob(f"{d}/pmc_{kind}/vm/*_counter_collection.csv")
+        f = sorted(glob.glob(f"{d}/pmc_{kind}/vm/*_counter_collection.csv"), key=os.path.getmtime, reverse=True)
         if not f:
             continue
         agg = collections.defaultdict(lambda: [0, 0.0])
@@ -43,7 +44,7 @@ for d in sorted(glob.glob("gpurun_out/prof_*")):
         lines += [f"bench under rocprof: {bench['value']} {bench['unit']}, {bench['ms_per_step']} ms/frame; dominant kernel "
                   f"`{rf.get('kernel')}` {rf.get('kernel_ms')} ms by HIP events, {rf.get('achieved')} GB/s algorithmic "
                   f"(frac {rf.get('frac')}).  With the profiler attached the launch's event pair reads a few µs above "
-                  f"the dispatch time below; in an un-profiled run it reads the same (bench_default_cfg2.json; DESIGN.md §5).", ""]
+                  f"the dispatch time below; in an un-profiled run it reads the same (DESIGN.md §5).", ""]
     lines += ["| kernel | calls | avg ns (kernel-trace) | FETCH_SIZE KiB | WRITE_SIZE KiB | traffic MB (2F+W) |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(stats[0])):
         k = r["Name"]
