@@ -19,6 +19,8 @@
 //
 // All kernels are HBM-bound streaming kernels: one entity per lane, no MFMA.
 #pragma once
+#include <utility>
+
 #include "yh_math.hpp"
 
 #define YH_K_MAX_FRUSTA 8
@@ -59,13 +61,39 @@ __host__ __device__ __forceinline__ uint64_t eoff(uint32_t e) {
 template <bool STREAM = false>
 __device__ __forceinline__ float lde(const float* __restrict__ base, uint64_t off, int q) {
     const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off + q * 256);
+#if defined(YH_LOAD_POLICY)
+    if (STREAM) {
+        float v;
+#if YH_LOAD_POLICY == 1
+        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+#elif YH_LOAD_POLICY == 2
+        asm volatile("global_load_dword %0, %1, off sc1 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+#endif
+        return v;
+    }
+#endif
     if (STREAM) return __builtin_nontemporal_load(p);  // read-once inputs of a scene too large for the Infinity Cache
     return *p;
 }
 // World matrices are written once per frame and read back at most by the next level: streaming (nontemporal)
 // stores keep them from evicting the parents and inputs other waves still need (measured +3..5 % per frame).
+// (YH_STORE_POLICY, YH_LOAD_POLICY: experiment builds only — tools/ab_cache_policy.sh compiles the library once per
+// cache-policy variant of the streaming accesses; the default build defines neither.)
 __device__ __forceinline__ void ste(float* __restrict__ base, uint64_t off, int q, float v) {
-    __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off + q * 256));
+    float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off + q * 256);
+#if !defined(YH_STORE_POLICY)
+    __builtin_nontemporal_store(v, p);
+#elif YH_STORE_POLICY == 1
+    *p = v;
+#elif YH_STORE_POLICY == 2
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif YH_STORE_POLICY == 3
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#elif YH_STORE_POLICY == 4
+    asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+#elif YH_STORE_POLICY == 5
+    asm volatile("global_store_dword %0, %1, off sc0 nt" ::"v"(p), "v"(v) : "memory");
+#endif
 }
 template <int NP, bool STREAM = false>
 __device__ __forceinline__ void load_row(const float* __restrict__ base, uint32_t e, float (&out)[NP]) {
@@ -73,6 +101,46 @@ __device__ __forceinline__ void load_row(const float* __restrict__ base, uint32_
 #pragma unroll
     for (int q = 0; q < NP; ++q) out[q] = lde<STREAM>(base, off, q);
 }
+// World matrices of the fused frame kernels: streaming stores that also DROP the line from the XCD's L2 (`sc1 nt`;
+// `nt` alone keeps it there).  Written once per frame, read at most by a later launch (through the Infinity Cache) or
+// by a consumer: measured against nt / plain / sc1 / sc0 sc1 / sc0 nt (profiles/r02/ab_store_policy.txt) cfg5's
+// kernel 4.543 -> 4.490 ms, cfg3's 0.367 -> 0.356, cfg4's 0.2842 -> 0.2824; plain stores 4.623 / 0.381 / 0.309.
+// One 64-bit row address, the plane as the instruction's immediate offset (as the compiler addresses store_row).
+// PACED (the flat kernels, whose waves do nothing but stream): sixteen stores issued back to back fill the CU's
+// memory pipeline and hold up the other waves' loads behind them; a few idle issue slots after each store let those
+// loads in between (profiles/r02/ab_store_pace.txt: s_nop 0 / 7 / 11 / 15, s_sleep 1 / 2 -> cfg5 4.510 / 4.490 /
+// 4.484 / 4.485 / 4.479 / 4.494 ms, cfg3 0.3601 / 0.3575 / 0.3569 / 0.3568 / 0.3584 / 0.3596).  Tree levels, whose
+// waves wait on their parents' rows anyway, were 0.3 % slower paced (cfg4) and stay unpaced.
+#if !defined(YH_STORE_PACE)
+#define YH_STORE_PACE 11
+#endif
+template <int Q, bool PACED>
+__device__ __forceinline__ void ste_world(float* row, float v) {
+    if (PACED) {
+#if YH_STORE_PACE >= 100
+        asm volatile("global_store_dword %0, %1, off offset:%2 sc1 nt\n\ts_sleep %3" ::"v"(row), "v"(v), "n"(Q * 256), "n"(YH_STORE_PACE - 100) : "memory");
+#else
+        asm volatile("global_store_dword %0, %1, off offset:%2 sc1 nt\n\ts_nop %3" ::"v"(row), "v"(v), "n"(Q * 256), "n"(YH_STORE_PACE) : "memory");
+#endif
+    } else {
+        asm volatile("global_store_dword %0, %1, off offset:%2 sc1 nt" ::"v"(row), "v"(v), "n"(Q * 256) : "memory");
+    }
+}
+template <bool PACED, int... Q>
+__device__ __forceinline__ void store_world_row_impl(float* row, const float (&v)[16], std::integer_sequence<int, Q...>) {
+    (ste_world<Q, PACED>(row, v[Q]), ...);
+}
+template <int NP>
+__device__ __forceinline__ void store_row(float* __restrict__ base, uint32_t e, const float (&v)[NP]);
+template <bool PACED>
+__device__ __forceinline__ void store_world_row(float* __restrict__ base, uint32_t e, const float (&v)[16]) {
+#if defined(YH_WORLD_STORES_NT_ONLY)  // experiment build: round 1's `nt` stores (tools/ab_cache_policy.sh)
+    store_row<16>(base, e, v);
+    return;
+#endif
+    store_world_row_impl<PACED>(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + eoff<16>(e)), v, std::make_integer_sequence<int, 16>{});
+}
+
 template <int NP>
 __device__ __forceinline__ void store_row(float* __restrict__ base, uint32_t e, const float (&v)[NP]) {
     const uint64_t off = eoff<NP>(e);
@@ -354,7 +422,7 @@ __device__ __forceinline__ void frame_trs_tile(const FrameArgs& a, const uint32_
         for (int q = 0; q < 16; ++q) w.v[q] = a.root[q];
     }
     w = m4_mul(w, m4_compose(in.t[0], in.t[1], in.t[2], in.t[3], in.t[4], in.t[5], in.t[6], in.t[7], in.t[8], in.t[9]));
-    if (valid) store_row<16>(a.world, e, w.v);
+    if (valid) store_world_row<!HAS_BASE>(a.world, e, w.v);
     if (BOUNDS != 0) {
         uint32_t vmask = 0, bmask = 0;
         cull_entity<BOUNDS>(a, w, in.b, in.mesh, vmask, bmask);
@@ -411,7 +479,7 @@ __device__ __forceinline__ void frame_chain_tile(const FrameArgs& a, const uint3
     }
     w = m4_mul(w, m4_compose(cur.t[0], cur.t[1], cur.t[2], cur.t[3], cur.t[4], cur.t[5], cur.t[6], cur.t[7], cur.t[8],
                              cur.t[9]));
-    if (valid) store_row<16>(a.world, e, w.v);
+    if (valid) store_world_row<false>(a.world, e, w.v);
     if (BOUNDS != 0) {
         uint32_t vmask = 0, bmask = 0;
         cull_entity<BOUNDS>(a, w, cur.b, cur.mesh, vmask, bmask);
@@ -467,7 +535,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_frame_trs_lds(const FrameArgs a) {
     }
     if (!wave_on) return;
     w = m4_mul(w, m4_compose(in.t[0], in.t[1], in.t[2], in.t[3], in.t[4], in.t[5], in.t[6], in.t[7], in.t[8], in.t[9]));
-    if (valid) store_row<16>(a.world, e, w.v);
+    if (valid) store_world_row<false>(a.world, e, w.v);
     if (BOUNDS != 0) {
         uint32_t vmask = 0, bmask = 0;
         cull_entity<BOUNDS>(a, w, in.b, in.mesh, vmask, bmask);
