@@ -202,6 +202,22 @@ int yh_scene_track_changes(yh_scene* s, int enable);
 int yh_get_changed_count(yh_scene* s, uint64_t* n_changed);
 int yh_download_changed_aos68(yh_scene* s, uint32_t* slots, void* world_rows, void* local_rows, uint64_t cap,
                               uint64_t* written);
+/* The same rows as two lists, one per component, each fetched on its own and STREAMED (what a host that copies the
+ * rows into many small tables wants: GpuTransformCullSystem.c).  A tracked frame files every row it touched under
+ *   which = 0: WorldTransform changed (recomputed, or its dirty flag was set) - the list of yh_download_changed_aos68;
+ *   which = 1: LocalTransform changed (the reverse branch re-derived it, TransformSyncSystem.zig:69-72, or its dirty
+ *              flag was set).  A parent that moves changes every WorldTransform below it and no LocalTransform: half
+ *              the bytes of yh_download_changed_aos68 stay on the device.
+ * yh_download_changed_rows_aos68 copies list `which` (slots ascending, may be NULL) and its 68-byte rows, dirty bytes
+ * cleared.  The rows arrive in up to 16 pieces per 4M rows, back to back on the link; after each piece
+ * `ready(user, rows_ready)` is called ON THE CALLING THREAD (NULL: no calls): rows [0, rows_ready) and all slots are
+ * in place, so helper threads of the caller can place them while the next piece is in flight.  Page-locked `rows`
+ * (yh_host_alloc) keep the copies asynchronous; ordinary memory works, each piece then completes inside its copy.
+ * cap too small: YH_ERR_CAPACITY with *written = rows needed, nothing copied.                                    */
+typedef void (*yh_rows_ready_fn)(void* user, uint64_t rows_ready);
+int yh_get_changed_counts(yh_scene* s, uint64_t* n_world, uint64_t* n_local);
+int yh_download_changed_rows_aos68(yh_scene* s, int which, uint32_t* slots, void* rows, uint64_t cap, uint64_t* written,
+                                   yh_rows_ready_fn ready, void* user);
 /* ---- draw-list consumer ------------------------------------------------------------------------
  * What the reference's draw loop does on the CPU for every object it is handed, here on the device for the visible
  * entities of one frustum, in list order i = 0 .. count-1:

@@ -236,8 +236,28 @@ def test_sparse_rows_and_change_tracking(ctx, oracle):
             assert np.isin(touched, slots).all(), tag
             if expect_changed is not None:
                 assert slots.size == expect_changed, f"{tag}: {slots.size} rows returned"
+            # the same rows as two streamed lists (yh_download_changed_rows_aos68): WorldTransform rows = the list above;
+            # LocalTransform rows = exactly the rows whose local flag was set or that took the reverse branch
+            pieces = []
+            sw, rw2 = s.changed_rows(0, on_ready=pieces.append)
+            sl, rl2 = s.changed_rows(1)
+            assert (len(sw), len(sl)) == s.changed_counts(), tag
+            assert np.array_equal(sw, slots) and np.array_equal(rw2, rw), tag
+            assert pieces == sorted(pieces) and (not len(sw) or pieces[-1] == len(sw)), f"{tag}: pieces {pieces}"
+            wd_after = np.zeros(n, bool)
+            reverse = np.zeros(n, bool)
+            for lv in range(len(lo) - 1):
+                a, b = int(lo[lv]), int(lo[lv + 1])
+                pd = wd_after[par[a:b]] if lv else np.zeros(b - a, bool)
+                ld, wd = before_l["dirty"][a:b] != 0, before_w["dirty"][a:b] != 0
+                wd_after[a:b] = pd | ld | wd
+                reverse[a:b] = wd & ~ld & ~pd
+            assert np.array_equal(sw, np.flatnonzero(wd_after)), tag
+            assert np.array_equal(sl, np.flatnonzero(reverse | (before_l["dirty"] != 0))), f"{tag}: LocalTransform list"
+            assert np.array_equal(rl2, rl[np.searchsorted(slots, sl)]), tag
+            assert np.isin(np.flatnonzero(np.any(local["m"].view(np.uint32) != before_l["m"].view(np.uint32), axis=1)), sl).all(), tag
             mirror_w[slots] = rw
-            mirror_l[slots] = rl
+            mirror_l[sl] = rl2  # the split lists alone keep the host's columns equal to the oracle's
             mirror_w["dirty"] = 0  # PostTransformSystem on the host side of a row that was dirty is in the returned rows;
             mirror_l["dirty"] = 0  # rows not returned were clean already
             oracle_w, oracle_l = world.copy(), local.copy()

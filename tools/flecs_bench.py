@@ -40,3 +40,6 @@ with tempfile.TemporaryDirectory() as d:
         r = subprocess.run([binary, scene, os.path.join(d, "out.bin")], env=e, capture_output=True, text=True, timeout=1200)
         times = [line.split(": ")[1].split(" ms")[0] for line in r.stderr.splitlines() if line.startswith("frame ")]
         print(f"{label:90s} n={n} L={levels}  ms per frame: " + "  ".join(times), flush=True)
+        for line in r.stderr.splitlines():
+            if line.startswith("stages ") and env in ({}, {"YFH_THREADS": "1"}):
+                print("    " + line, flush=True)

@@ -78,6 +78,8 @@ _u32 = C.c_uint32
 _int = C.c_int
 
 # name -> (restype, argtypes); every function include/yume_hip.h declares
+ROWS_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64)  # yh_rows_ready_fn
+
 SIGNATURES = {
     "yh_abi_version": (_u32, []),
     "yh_init": (_int, [_int, C.POINTER(_vp)]),
@@ -116,6 +118,8 @@ SIGNATURES = {
     "yh_scene_track_changes": (_int, [_vp, _int]),
     "yh_get_changed_count": (_int, [_vp, C.POINTER(_u64)]),
     "yh_download_changed_aos68": (_int, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
+    "yh_get_changed_counts": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "yh_download_changed_rows_aos68": (_int, [_vp, _int, _vp, _vp, _u64, C.POINTER(_u64), _vp, _vp]),
     "yh_upload_vertex_counts": (_int, [_vp, _vp, _u64]),
     "yh_build_object_data": (_int, [_vp, _u32, _u32]),
     "yh_get_object_data": (_int, [_vp, _u32, _vp, _vp, _u64, C.POINTER(_u64)]),

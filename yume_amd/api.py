@@ -313,6 +313,25 @@ class Scene:
         self._ck(L.lib().yh_download_changed_aos68(self._h, _ptr(slots), _ptr(w), _ptr(l), n.value, C.byref(wr)))
         return slots, w, l
 
+    def changed_counts(self):
+        """(rows whose WorldTransform changed, rows whose LocalTransform changed) in the last tracked frame."""
+        nw, nl = C.c_uint64(), C.c_uint64()
+        self._ck(L.lib().yh_get_changed_counts(self._h, C.byref(nw), C.byref(nl)))
+        return nw.value, nl.value
+
+    def changed_rows(self, which, on_ready=None):
+        """(slots, rows) of one component's changed rows (which: 0 WorldTransform, 1 LocalTransform), streamed:
+        on_ready(rows_ready) is called after each piece has landed."""
+        n = self.changed_counts()[which]
+        slots = np.zeros(n, np.uint32)
+        rows = np.zeros(n, T68)
+        wr = C.c_uint64()
+        cb = L.ROWS_READY_FN((lambda user, r: on_ready(int(r))) if on_ready else 0)
+        self._ck(L.lib().yh_download_changed_rows_aos68(self._h, which, _ptr(slots), _ptr(rows), n, C.byref(wr),
+                                                        C.cast(cb, C.c_void_p), None))
+        assert wr.value == n
+        return slots, rows
+
     def compose(self, first=0, count=None):
         count = self.n - first if count is None else count
         out = np.empty((16, count), np.float32)

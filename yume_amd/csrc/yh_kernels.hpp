@@ -598,6 +598,11 @@ __global__ __launch_bounds__(YH_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) v
     if (tile < a.n_tiles) frame_chain_tile<G, BOUNDS, false>(a, tile);
 }
 
+// WorldTransform.dirty on the device is "non-zero".  A row that took the reverse branch (its LOCAL matrix was re-derived,
+// TransformSyncSystem.zig:69-72) carries this value instead of 1 until the frame's sweep, which files it under the rows
+// whose LocalTransform has to go back to the host; every other reader tests != 0 only.  (Uploads normalise to 0 / 1.)
+#define YH_WDIRTY_LOCAL_REWRITTEN 3
+
 // ---------------------------------------------------------------------------------------------------
 // Dirty-aware level kernel, Mat4 locals (imported flecs columns): the literal three-branch rule of
 // TransformSyncSystem.zig:60-73, one level per launch (the parent's dirty flag must already be this
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, cons
 #pragma unroll
                 for (int q = 0; q < 16; ++q) pm.v[q] = a.root[q];
             }
-            a.wdirty[e] = 1;  // :65
+            a.wdirty[e] = (ld || pd) ? 1 : YH_WDIRTY_LOCAL_REWRITTEN;  // :65 (non-zero = dirty; see k_sweep_dirty)
             if (ld || pd) {   // :67-68
                 M4 l;
                 load_row<16, BIG>(a.lmat, e, l.v);
@@ -667,11 +672,12 @@ __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, cons
 // its stored world matrix (clean, or edited in world space: the reverse branch leaves the world matrix alone), and
 // "dirty" propagates exactly as WorldTransform.dirty does level by level.  The entity's own row then goes through
 // the literal three branches.  Flags read from an ancestor may already have been rewritten by that ancestor's own
-// lane in this launch: the only rewrite is wdirty 0 -> 1 on a row the rule found dirty anyway, so the replay's
+// lane in this launch: the only rewrite is wdirty -> non-zero on a row the rule found dirty anyway, so the replay's
 // outcome is the same; world[a] is only rewritten in the forward branch, where the replay does not read it; lmat[a]
 // only in the reverse branch, where the replay does not read it either.
 // INVARIANT (a checkable rule for whoever adds a writer to a level launch): inside k_level_mat4 / k_chain_mat4 the only
-// store to wdirty is 0 -> 1 on the lane's OWN row, no launch clears a flag (that is k_clear_dirty / k_sweep_dirty's
+// store to wdirty is "to a non-zero value" (1, or 3 on a reverse-branch row whose flag was non-zero already) on the lane's
+// OWN row, every reader tests != 0 only, no launch clears a flag (that is k_clear_dirty / k_sweep_dirty's
 // job, after the last level), a lane stores world[e] only where ld || pd and lmat[e] only where !(ld || pd) && wd of
 // its own row e, and a replay reads world[anc] only where !(ld_anc || pd) and lmat[anc] only where ld_anc || pd: the
 // sets "rows a lane may store" and "rows a replay may load" are disjoint per array.  Pinned by
@@ -731,7 +737,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_chain_mat4(const FrameArgs a, cons
         const bool wd = a.wdirty[e] != 0;
         M4 w;
         if (pd || ld || wd) {  // TransformSyncSystem.zig:62-64
-            a.wdirty[e] = 1;   // :65
+            a.wdirty[e] = (ld || pd) ? 1 : YH_WDIRTY_LOCAL_REWRITTEN;  // :65
             if (ld || pd) {    // :67-68
                 M4 l;
                 load_row<16>(a.lmat, e, l.v);
@@ -769,19 +775,27 @@ __global__ __launch_bounds__(YH_BLOCK) void k_count(const ExpandArgs x) {
 
 __global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) { expand_tile(x, blockIdx.x, blockIdx.y); }
 
-// The same sweep when changes are tracked (yh_scene_track_changes): one wave per 64-entity chunk first publishes
-// the ballot of "LocalTransform.dirty or WorldTransform.dirty" — every row this frame recomputed or found edited —
-// as the chunk's word of the change mask, then clears both flags.  k_count / k_expand turn the mask into the
-// ascending list of changed slots, exactly as they do for a frustum.
+// The same sweep when changes are tracked (yh_scene_track_changes): one wave per 64-entity chunk first publishes two
+// ballots as the chunk's words of the two change masks, then clears both flags.
+//   mask 0: LocalTransform.dirty or WorldTransform.dirty - every row this frame recomputed or found edited (its
+//           WorldTransform row, matrix or flag, differs from what the host holds);
+//   mask 1: LocalTransform.dirty, or the frame re-derived the local matrix (reverse branch) - the rows whose
+//           LocalTransform differs from what the host holds.  A root that moves dirties every world matrix below it and
+//           not one local matrix: only mask 0's rows need to cross PCIe.
+// k_count / k_expand turn the masks into ascending lists of slots, exactly as they do for two frusta.
 __global__ __launch_bounds__(YH_BLOCK) void k_sweep_dirty(uint8_t* __restrict__ ld, uint8_t* __restrict__ wd, uint32_t n,
-                                                          uint64_t* __restrict__ words, uint8_t* __restrict__ counts) {
+                                                          uint64_t* __restrict__ words, uint8_t* __restrict__ counts,
+                                                          uint32_t n_chunks, uint32_t cnt_stride) {
     const uint64_t e = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;  // the grid covers whole chunks
     const bool in = e < n;
-    const bool changed = in && ((ld[e] | wd[e]) != 0);
-    const uint64_t m = __ballot(changed);
+    const uint32_t l = in ? ld[e] : 0u, w = in ? wd[e] : 0u;
+    const uint64_t m = __ballot((l | w) != 0);
+    const uint64_t ml = __ballot(l != 0 || w == YH_WDIRTY_LOCAL_REWRITTEN);
     if ((threadIdx.x & 63u) == 0 && e < (((uint64_t)n + 63u) & ~63ull)) {  // the last workgroup may reach past the last chunk
         words[e >> 6] = m;
         counts[e >> 6] = (uint8_t)__popcll(m);
+        words[(uint64_t)n_chunks + (e >> 6)] = ml;
+        counts[(uint64_t)cnt_stride + (e >> 6)] = (uint8_t)__popcll(ml);
     }
     if (in) {
         ld[e] = 0;

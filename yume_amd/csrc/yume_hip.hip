@@ -23,6 +23,11 @@
 
 static_assert(YH_MAX_FRUSTA == YH_K_MAX_FRUSTA, "header / kernel frustum limits differ");
 
+// yh_download_changed_rows_aos68: rows gathered per kernel, copies per kernel, smallest copy worth an event
+#define YH_DL_ROWS_MAX (4ull << 20)
+#define YH_DL_PIECES 16
+#define YH_DL_PIECE_ROWS_MIN 32768ull
+
 // ------------------------------------------------------------------------------------------------ state
 struct yh_ctx {
     int device = -1;
@@ -87,7 +92,10 @@ struct yh_scene {
     uint32_t* chg = nullptr;          // device: 32 count words | tile counts | mask words (one allocation)
     uint32_t* chg_tilecnt = nullptr;
     uint64_t* chg_words = nullptr;
-    uint32_t* chg_list = nullptr;     // device: changed slots of the last frame
+    uint32_t* chg_list = nullptr;     // device: changed slots of the last frame (WorldTransform rows: mask 0)
+    uint32_t* chg_list_l = nullptr;   // device: slots whose LocalTransform row changed (mask 1)
+    hipEvent_t piece_ev[YH_DL_PIECES] = {};  // yh_download_changed_rows_aos68: one per piece in flight
+    bool piece_ev_made = false;
     uint32_t* h_chg = nullptr;        // host-mapped totals written by k_expand
     uint32_t* h_chg_dev = nullptr;
     bool chg_valid = false;           // a tracked frame has run since tracking was enabled
@@ -309,7 +317,7 @@ static void scene_free(yh_scene* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->ctx->stream_c) (void)hipStreamSynchronize(s->ctx->stream_c);
     void* ptrs[] = {s->trs, s->lmat, s->world, s->parent, s->bounds, s->mesh_id, s->ldirty, s->wdirty, s->counts,
-                    s->staging, s->d_all_counts, s->chg, s->chg_list};
+                    s->staging, s->d_all_counts, s->chg, s->chg_list, s->chg_list_l};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->vcount) (void)hipFree(s->vcount);
@@ -326,6 +334,8 @@ static void scene_free(yh_scene* s) {
     if (s->h_chg) (void)hipHostFree(s->h_chg);
     if (s->h_all_counts) (void)hipHostFree(s->h_all_counts);
     if (s->ev_frame) (void)hipEventDestroy(s->ev_frame);
+    for (hipEvent_t e : s->piece_ev)
+        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : s->ev_mask)
         if (e) (void)hipEventDestroy(e);
     for (void* p : {(void*)s->d_peer, (void*)s->gmask, (void*)s->send_pad, (void*)s->gtile, (void*)s->mask_alt, (void*)s->viscnt_alt})
@@ -824,13 +834,15 @@ extern "C" int yh_scene_track_changes(yh_scene* s, int enable) {
     if (int rc = sync_scene(s)) return rc;
     if (enable && !s->chg) {
         const uint64_t tile_words = ((uint64_t)s->n_tiles + 1) & ~1ull;
-        const uint64_t bytes = (32 + tile_words) * 4 + (uint64_t)s->n_chunks * 8 + s->cnt_stride + 16;
+        // two masks (k_sweep_dirty), laid out as two frusta of a visibility set: [mask][n_tiles | n_chunks | cnt_stride]
+        const uint64_t bytes = (32 + 2 * tile_words) * 4 + 2 * (uint64_t)s->n_chunks * 8 + 2 * (uint64_t)s->cnt_stride + 16;
         HIP_TRY(ctx, hipMalloc((void**)&s->chg, bytes));
         HIP_TRY(ctx, hipMemsetAsync(s->chg, 0, bytes, ctx->stream));  // ordered with the frames: not the null stream
         s->chg_tilecnt = s->chg + 32;
-        s->chg_words = (uint64_t*)(s->chg_tilecnt + tile_words);
-        s->chg_cnt = (uint8_t*)(((uintptr_t)(s->chg_words + s->n_chunks) + 15) & ~(uintptr_t)15);
+        s->chg_words = (uint64_t*)(s->chg_tilecnt + 2 * tile_words);
+        s->chg_cnt = (uint8_t*)(((uintptr_t)(s->chg_words + 2 * (uint64_t)s->n_chunks) + 15) & ~(uintptr_t)15);
         HIP_TRY(ctx, hipMalloc((void**)&s->chg_list, s->stride * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&s->chg_list_l, s->stride * 4));
         HIP_TRY(ctx, hipHostMalloc((void**)&s->h_chg, 2 * YH_MAX_FRUSTA * 4, hipHostMallocMapped));
         HIP_TRY(ctx, hipHostGetDevicePointer((void**)&s->h_chg_dev, s->h_chg, 0));
         memset(s->h_chg, 0, 2 * YH_MAX_FRUSTA * 4);
@@ -865,6 +877,67 @@ extern "C" int yh_download_changed_aos68(yh_scene* s, uint32_t* slots, void* wor
         if (int rc = download_aos68(s, world_rows, 0, n, s->world, s->wdirty, s->chg_list)) return rc;
     if (local_rows)
         if (int rc = download_aos68(s, local_rows, 0, n, s->lmat, s->ldirty, s->chg_list)) return rc;
+    return YH_OK;
+}
+
+extern "C" int yh_get_changed_counts(yh_scene* s, uint64_t* n_world, uint64_t* n_local) {
+    if (!s || !n_world || !n_local) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_get_changed_counts: NULL argument");
+    if (!s->track || !s->chg_valid) return fail(s->ctx, YH_ERR_STATE, "yh_get_changed_counts: no tracked frame has run");
+    if (s->frame_pending)
+        if (int rc = sync_scene(s)) return rc;
+    *n_world = s->h_chg[0];
+    *n_local = s->h_chg[1];
+    return YH_OK;
+}
+
+// One column of the changed rows, STREAMED: one kernel gathers every listed row into 68-byte rows on the device, the
+// rows then cross PCIe as YH_DL_PIECES-or-fewer back-to-back copies (nothing between them on the stream: the link
+// never idles), and `ready` hears of each piece as its event completes - the caller copies piece i into its tables
+// while piece i + 1 is in flight.
+extern "C" int yh_download_changed_rows_aos68(yh_scene* s, int which, uint32_t* slots, void* rows, uint64_t cap,
+                                              uint64_t* written, yh_rows_ready_fn ready, void* user) {
+    if (!s || !written) return fail(s ? s->ctx : nullptr, YH_ERR_BAD_ARG, "yh_download_changed_rows_aos68: NULL argument");
+    yh_ctx* ctx = s->ctx;
+    ARG_TRY(ctx, which == 0 || which == 1, "yh_download_changed_rows_aos68: which must be 0 (WorldTransform) or 1 (LocalTransform)");
+    uint64_t nw = 0, nl = 0;
+    if (int rc = yh_get_changed_counts(s, &nw, &nl)) return rc;
+    const uint64_t n = which ? nl : nw;
+    *written = n;
+    if (n > cap) return fail(ctx, YH_ERR_CAPACITY, "yh_download_changed_rows_aos68: %llu rows changed, room for %llu",
+                             (unsigned long long)n, (unsigned long long)cap);
+    if (n == 0) return YH_OK;
+    ARG_TRY(ctx, rows, "yh_download_changed_rows_aos68: rows is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_scene(s)) return rc;
+    if (!s->piece_ev_made) {
+        for (hipEvent_t& e : s->piece_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s->piece_ev_made = true;
+    }
+    const uint32_t* list = which ? s->chg_list_l : s->chg_list;
+    const float* planes = which ? s->lmat : s->world;
+    const uint8_t* dirty = which ? s->ldirty : s->wdirty;  // cleared by the sweep: rows come back with dirty = 0
+    hipStream_t st = ctx->stream;
+    if (slots) HIP_TRY(ctx, hipMemcpyAsync(slots, list, n * 4, hipMemcpyDeviceToHost, st));
+    // device staging for at most YH_DL_ROWS_MAX rows at a time (a 256M-row column does not get a 17 GB twin)
+    if (int rc = ensure_staging(s, std::min<uint64_t>(n, YH_DL_ROWS_MAX) * 68)) return rc;
+    char* dst = (char*)rows;
+    for (uint64_t base = 0; base < n; base += YH_DL_ROWS_MAX) {
+        const uint64_t c = std::min<uint64_t>(YH_DL_ROWS_MAX, n - base);
+        hipLaunchKernelGGL(k_soa_to_aos68, dim3(cdiv(c, YH_BLOCK)), dim3(YH_BLOCK), 0, st, planes, dirty, base, c,
+                           (uint32_t*)s->staging, list);
+        HIP_TRY(ctx, hipGetLastError());
+        const uint64_t piece = std::max<uint64_t>(YH_DL_PIECE_ROWS_MIN, cdiv(c, YH_DL_PIECES));
+        uint32_t pieces = 0;
+        for (uint64_t r = 0; r < c; r += piece, ++pieces) {
+            const uint64_t pc = std::min<uint64_t>(piece, c - r);
+            HIP_TRY(ctx, hipMemcpyAsync(dst + (base + r) * 68, (const char*)s->staging + r * 68, pc * 68, hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipEventRecord(s->piece_ev[pieces], st));
+        }
+        for (uint32_t i = 0; i < pieces; ++i) {
+            HIP_TRY(ctx, hipEventSynchronize(s->piece_ev[i]));
+            if (ready) ready(user, std::min<uint64_t>(n, base + (uint64_t)(i + 1) * piece));
+        }
+    }
     return YH_OK;
 }
 
@@ -1320,7 +1393,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
         // PostWorldTransform / PostLocalTransform (PostTransformSystem.zig:12-37)
         if (s->track) {
             hipLaunchKernelGGL(k_sweep_dirty, dim3(cdiv(s->stride, YH_BLOCK)), dim3(YH_BLOCK), 0, st, s->ldirty, s->wdirty,
-                               (uint32_t)s->n, s->chg_words, s->chg_cnt);
+                               (uint32_t)s->n, s->chg_words, s->chg_cnt, s->n_chunks, s->cnt_stride);
             HIP_TRY(ctx, hipGetLastError());
             ExpandArgs c;
             memset(&c, 0, sizeof c);
@@ -1333,13 +1406,14 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
             c.bcount_next = s->chg + 2 * YH_MAX_FRUSTA;
             c.host_counts = s->h_chg_dev;
             c.draw[0] = s->chg_list;
+            c.draw[1] = s->chg_list_l;
             c.draw_cap = s->stride;
             c.n_chunks = s->n_chunks;
             c.n_tiles = s->n_tiles;
             c.words = s->tile_words;
             c.self_count = (s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES && s->tile_words <= 64u);
-            if (!c.self_count) hipLaunchKernelGGL(k_count, dim3(s->n_tiles, 1), dim3(YH_BLOCK), 0, st, c);
-            hipLaunchKernelGGL(k_expand, dim3(s->n_tiles, 1), dim3(YH_BLOCK), 0, st, c);
+            if (!c.self_count) hipLaunchKernelGGL(k_count, dim3(s->n_tiles, 2), dim3(YH_BLOCK), 0, st, c);
+            hipLaunchKernelGGL(k_expand, dim3(s->n_tiles, 2), dim3(YH_BLOCK), 0, st, c);
             HIP_TRY(ctx, hipGetLastError());
             s->chg_valid = true;
             launches += c.self_count ? 2 : 3;

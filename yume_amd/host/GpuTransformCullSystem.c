@@ -23,14 +23,17 @@
 #include "GpuTransformCullSystem.h"
 
 #include <pthread.h>
+#include <sched.h>
+#include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #define ROW 68u
 #define MAX_THREADS 32
 #define MESH_TABLE_MAX 65536u /* distinct meshes (+ entities with bounds of their own) a mesh-table scene can hold */
-#define ROWS_PER_THREAD_MIN 8192u /* below this many changed rows per helper a thread costs more than it saves */
+#define ROWS_PER_THREAD_MIN 2048u /* below this many changed rows per helper a thread costs more than it saves */
 
 typedef struct Batch {
     void* world_col;
@@ -129,8 +132,10 @@ struct GpuTransformCullSystem {
     uint32_t* stamp[2];      /* per slot: frame in which the row was last queued (duplicates in the dirty lists) */
     uint32_t epoch;
     uint32_t* slot_buf;      /* n entries: slots of a sparse upload / of the changed rows */
+    int slot_buf_pinned;
     ecs_entity_t observers[7];
     uint64_t last_up_rows, last_down_rows;
+    double last_ms[4];       /* the last frame's wall time: tables + inputs, rows up, device frame, rows down and placed */
 
     int status;
     uint64_t rebuilds;
@@ -427,8 +432,12 @@ static int rebuild(GpuTransformCullSystem* s) {
         free(s->stamp[k]);
         s->stamp[k] = (uint32_t*)calloc((size_t)(n ? n : 1), sizeof(uint32_t));
     }
-    free(s->slot_buf);
-    s->slot_buf = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n ? n : 1));
+    /* the slots of sparse uploads / changed rows cross PCIe too: page-locked like the staging columns when possible */
+    if (s->slot_buf_pinned) yh_host_free(s->ctx, s->slot_buf);
+    else free(s->slot_buf);
+    s->slot_buf = (uint32_t*)yh_host_alloc(s->ctx, sizeof(uint32_t) * (uint64_t)(n ? n : 1));
+    s->slot_buf_pinned = s->slot_buf != NULL;
+    if (!s->slot_buf) s->slot_buf = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n ? n : 1));
     s->epoch = 0;
     if (!s->stamp[0] || !s->stamp[1] || !s->slot_buf) {
         rc = YH_ERR_OOM;
@@ -716,61 +725,110 @@ static int restore_walk(GpuTransformCullSystem* s, const ecs_iter_t* it) {
     return 1;
 }
 
-/* Changed rows [i0, i1) of the staging columns (ascending slots) back into their tables: runs of consecutive slots
- * inside one batch go in one copy.  Touches no shared state but the rows themselves (column pointers that are not
- * cached yet are looked up, not cached: several helpers may meet in one batch), so ranges can run side by side. */
-static void scatter_range(GpuTransformCullSystem* s, uint64_t i0, uint64_t i1) {
+/* Changed rows [i0, i1) of one staging column (k = 0 LocalTransform, 1 WorldTransform; ascending slots) back into their
+ * tables: runs of consecutive slots inside one batch go in one copy.  Touches no shared state but the rows themselves
+ * (column pointers that are not cached yet are looked up, not cached: several helpers may meet in one batch), so
+ * ranges can run side by side. */
+static void scatter_range(GpuTransformCullSystem* s, int k, const uint32_t* slots, const uint8_t* stage, uint64_t i0,
+                          uint64_t i1) {
     const Batch* b = NULL;
-    uint8_t *wcol = NULL, *lcol = NULL;
+    uint8_t* col = NULL;
     for (uint64_t i = i0; i < i1;) {
-        const uint32_t slot = s->slot_buf[i];
+        const uint32_t slot = slots[i];
         if (!b || slot < b->slot_begin || slot >= b->slot_begin + b->count) {
             b = &s->batches[s->batch_of[slot]];
-            wcol = (uint8_t*)(b->world_col ? b->world_col : ecs_table_get_column(b->table, b->col_w, 0));
-            lcol = (uint8_t*)(b->local_col ? b->local_col : ecs_table_get_column(b->table, b->col_l, 0));
+            if (k) col = (uint8_t*)(b->world_col ? b->world_col : ecs_table_get_column(b->table, b->col_w, 0));
+            else col = (uint8_t*)(b->local_col ? b->local_col : ecs_table_get_column(b->table, b->col_l, 0));
         }
         const uint32_t batch_end = b->slot_begin + b->count;
         uint64_t j = i + 1;
-        while (j < i1 && s->slot_buf[j] == slot + (uint32_t)(j - i) && s->slot_buf[j] < batch_end) ++j;
-        const size_t r = (size_t)(slot - b->slot_begin) * ROW, bytes = (size_t)(j - i) * ROW;
-        memcpy(wcol + r, s->stage_w + i * ROW, bytes);
-        memcpy(lcol + r, s->stage_l + i * ROW, bytes);
+        while (j < i1 && slots[j] == slot + (uint32_t)(j - i) && slots[j] < batch_end) ++j;
+        memcpy(col + (size_t)(slot - b->slot_begin) * ROW, stage + i * ROW, (size_t)(j - i) * ROW);
         i = j;
     }
 }
 
-typedef struct ScatterJob {
+/* The copy back is host-memory work on up to hundreds of thousands of small tables, and it is as long as the PCIe
+ * transfer itself: helpers share it and start while rows are still arriving.  The library delivers the rows in pieces
+ * (yh_download_changed_rows_aos68) and says how many are in place; every helper claims the next SCATTER_GRAIN rows,
+ * waits until they have landed and copies them into their tables.  Threads live for this one call: the system owns no
+ * thread between frames. */
+#define SCATTER_GRAIN 1024u
+typedef struct ScatterStream {
     GpuTransformCullSystem* s;
-    uint64_t i0, i1;
-} ScatterJob;
+    int k;
+    const uint32_t* slots;
+    const uint8_t* stage;
+    uint64_t total;
+    uint32_t helpers;        /* threads at work, the calling one included */
+    _Atomic uint64_t ready;  /* rows delivered so far */
+    _Atomic uint64_t cursor; /* next row nobody has claimed */
+    _Atomic int stop;        /* the download failed: rows that have not landed never will */
+} ScatterStream;
+
+static void scatter_work(ScatterStream* t) {
+    for (;;) {
+        const uint64_t i0 = atomic_fetch_add_explicit(&t->cursor, SCATTER_GRAIN, memory_order_relaxed);
+        if (i0 >= t->total) return;
+        const uint64_t i1 = i0 + SCATTER_GRAIN < t->total ? i0 + SCATTER_GRAIN : t->total;
+        while (atomic_load_explicit(&t->ready, memory_order_acquire) < i1) {
+            if (atomic_load_explicit(&t->stop, memory_order_relaxed)) return;
+            sched_yield();
+        }
+        scatter_range(t->s, t->k, t->slots, t->stage, i0, i1);
+    }
+}
 static void* scatter_thread(void* arg) {
-    ScatterJob* j = (ScatterJob*)arg;
-    scatter_range(j->s, j->i0, j->i1);
+    scatter_work((ScatterStream*)arg);
     return NULL;
 }
-
-/* The copy back is host-memory work on up to hundreds of thousands of small tables: helpers share it when there is
- * enough of it (threads live for this one call: the system owns no thread between frames). */
-static void scatter_changed(GpuTransformCullSystem* s, uint64_t m) {
-    uint64_t parts = m / ROWS_PER_THREAD_MIN;
-    if (parts > (uint64_t)s->threads) parts = (uint64_t)s->threads;
-    if (parts < 2) {
-        scatter_range(s, 0, m);
-        return;
-    }
+/* The first helper starts the others (and joins them), so the calling thread spends one pthread_create, not fifteen,
+ * before the copies start. */
+static void* scatter_first_helper(void* arg) {
+    ScatterStream* t = (ScatterStream*)arg;
     pthread_t th[MAX_THREADS];
-    ScatterJob job[MAX_THREADS];
     int started[MAX_THREADS];
-    for (uint64_t p = 0; p < parts; ++p) {
-        job[p].s = s;
-        job[p].i0 = m * p / parts;
-        job[p].i1 = m * (p + 1) / parts;
-        started[p] = p > 0 && pthread_create(&th[p], NULL, scatter_thread, &job[p]) == 0;
-    }
-    for (uint64_t p = 0; p < parts; ++p)
-        if (!started[p]) scatter_range(s, job[p].i0, job[p].i1); /* part 0, and any part whose thread did not start */
-    for (uint64_t p = 1; p < parts; ++p)
+    for (uint32_t p = 2; p < t->helpers; ++p) started[p] = pthread_create(&th[p], NULL, scatter_thread, t) == 0;
+    scatter_work(t);
+    for (uint32_t p = 2; p < t->helpers; ++p)
         if (started[p]) pthread_join(th[p], NULL);
+    return NULL;
+}
+static void scatter_rows_ready(void* user, uint64_t rows_ready) {
+    atomic_store_explicit(&((ScatterStream*)user)->ready, rows_ready, memory_order_release);
+}
+
+/* One component's changed rows: device -> staging column -> tables.  k = 0 LocalTransform, 1 WorldTransform. */
+static int fetch_changed(GpuTransformCullSystem* s, int k, uint64_t m) {
+    uint8_t* stage = k ? s->stage_w : s->stage_l;
+    const int which = k ? 0 : 1; /* the library's numbering: 0 WorldTransform, 1 LocalTransform */
+    uint64_t written = 0;
+    int rc;
+    uint64_t helpers = m / ROWS_PER_THREAD_MIN;
+    if (helpers > (uint64_t)s->threads) helpers = (uint64_t)s->threads;
+    if (helpers < 2) {
+        if ((rc = yh_download_changed_rows_aos68(s->scene, which, s->slot_buf, stage, s->n, &written, NULL, NULL)) != YH_OK) return rc;
+        if (written != m) return YH_ERR_STATE; /* (the counts were read a moment ago: they agree) */
+        scatter_range(s, k, s->slot_buf, stage, 0, written);
+        return YH_OK;
+    }
+    ScatterStream t;
+    t.s = s;
+    t.k = k;
+    t.slots = s->slot_buf;
+    t.stage = stage;
+    t.total = m;
+    atomic_init(&t.ready, 0);
+    atomic_init(&t.cursor, 0);
+    atomic_init(&t.stop, 0);
+    t.helpers = (uint32_t)helpers;
+    pthread_t first;
+    const int started = pthread_create(&first, NULL, scatter_first_helper, &t) == 0;
+    rc = yh_download_changed_rows_aos68(s->scene, which, s->slot_buf, stage, s->n, &written, scatter_rows_ready, &t);
+    if (rc != YH_OK || written != m) atomic_store(&t.stop, 1);
+    else scatter_work(&t); /* every row is in place: this thread joins in, and finishes alone if no helper started */
+    if (started) pthread_join(first, NULL);
+    return rc != YH_OK ? rc : (written == m ? YH_OK : YH_ERR_STATE);
 }
 
 /* Frames ran without readback and now the slot order is about to be rebuilt from the flecs columns (a structural
@@ -807,9 +865,65 @@ static int catch_up_by_entity(GpuTransformCullSystem* s) {
     return YH_OK;
 }
 
+/* The rows whose onSet fired, from their tables into the staging column (duplicates dropped, slots into slot_buf).
+ * Every row costs a chain of cache misses (entity -> slot map, stamp, slot -> batch, the batch, the row itself, all in
+ * tables far larger than the caches), so the chain is walked for GATHER_BLOCK rows at a time, each link prefetched for
+ * the whole block before the next link is followed: the misses of a block overlap instead of queueing up. */
+#define GATHER_BLOCK 64u
+static uint64_t gather_dirty(GpuTransformCullSystem* s, int k, uint8_t* stage) {
+    const uint64_t nd = s->n_dirty[k], mask = s->slot_of.cap - 1;
+    const ecs_entity_t* ents = s->dirty[k];
+    uint32_t* stamp = s->stamp[k];
+    uint64_t m = 0;
+    uint32_t slot[GATHER_BLOCK];
+    const uint8_t* src[GATHER_BLOCK];
+    for (uint64_t i0 = 0; i0 < nd; i0 += GATHER_BLOCK) {
+        const uint32_t nb = (uint32_t)(nd - i0 < GATHER_BLOCK ? nd - i0 : GATHER_BLOCK);
+        for (uint32_t j = 0; j < nb; ++j) __builtin_prefetch(&s->slot_of.e[hash64(ents[i0 + j]) & mask]);
+        for (uint32_t j = 0; j < nb; ++j) {
+            if (!map_get(&s->slot_of, ents[i0 + j], &slot[j])) {
+                slot[j] = UINT32_MAX; /* not a row of this system (the root, or an entity deleted since) */
+                continue;
+            }
+            __builtin_prefetch(&stamp[slot[j]]);
+            if (s->batch_of) __builtin_prefetch(&s->batch_of[slot[j]]);
+        }
+        for (uint32_t j = 0; j < nb; ++j) {
+            if (slot[j] == UINT32_MAX) continue;
+            if (stamp[slot[j]] == s->epoch) {
+                slot[j] = UINT32_MAX; /* set more than once since the last frame */
+                continue;
+            }
+            stamp[slot[j]] = s->epoch;
+            if (s->batch_of) __builtin_prefetch(&s->batches[s->batch_of[slot[j]]]);
+        }
+        for (uint32_t j = 0; j < nb; ++j) {
+            if (slot[j] == UINT32_MAX) continue;
+            const Batch* b = batch_of_slot(s, slot[j]);
+            src[j] = (const uint8_t*)(k == 0 ? b->local_col : b->world_col) + (size_t)(slot[j] - b->slot_begin) * ROW;
+            __builtin_prefetch(src[j]);
+            __builtin_prefetch(src[j] + 64);
+        }
+        for (uint32_t j = 0; j < nb; ++j) {
+            if (slot[j] == UINT32_MAX) continue;
+            memcpy(stage + m * ROW, src[j], ROW);
+            s->slot_buf[m++] = slot[j];
+        }
+    }
+    return m;
+}
+
+static double now_ms(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
 static void run(ecs_iter_t* it) {
     GpuTransformCullSystem* s = (GpuTransformCullSystem*)it->ctx;
     int rc = YH_OK;
+    const double t_begin = now_ms();
+    s->last_ms[0] = s->last_ms[1] = s->last_ms[2] = s->last_ms[3] = 0.0;
     int rebuilt = 0;
     /* Nothing structural happened since the batches were last brought up to date (no observer fired, the query's cache
      * matched or unmatched no table): they still are the world's tables, row for row.  No iteration, no validation. */
@@ -891,6 +1005,7 @@ static void run(ecs_iter_t* it) {
         s->n_frusta = nf;
     }
     const uint32_t cull_flags = s->n_frusta ? 0u : YH_FRAME_NO_CULL;
+    const double t_inputs = now_ms();
     if (!s->incremental || rebuilt) {
         /* whole columns up; in plain mode whole columns down again */
         for (uint32_t i = 0; i < s->n_batches; ++i) {
@@ -910,16 +1025,7 @@ static void run(ecs_iter_t* it) {
         s->last_up_rows = 0;
         for (int k = 0; k < 2; ++k) {
             uint8_t* stage = k == 0 ? s->stage_l : s->stage_w;
-            uint64_t m = 0;
-            for (uint64_t i = 0; i < s->n_dirty[k]; ++i) {
-                uint32_t slot;
-                if (!map_get(&s->slot_of, s->dirty[k][i], &slot) || s->stamp[k][slot] == s->epoch) continue;
-                s->stamp[k][slot] = s->epoch;
-                const Batch* b = batch_of_slot(s, slot);
-                const uint8_t* col = (const uint8_t*)(k == 0 ? b->local_col : b->world_col);
-                memcpy(stage + m * ROW, col + (size_t)(slot - b->slot_begin) * ROW, ROW);
-                s->slot_buf[m++] = slot;
-            }
+            const uint64_t m = gather_dirty(s, k, stage);
             rc = k == 0 ? yh_upload_local_rows_aos68(s->scene, s->slot_buf, stage, m)
                         : yh_upload_world_rows_aos68(s->scene, s->slot_buf, stage, m);
             if (rc != YH_OK) {
@@ -929,7 +1035,10 @@ static void run(ecs_iter_t* it) {
             s->last_up_rows += m;
         }
     }
-    if ((rc = yh_frame(s->scene, s->planes, s->n_frusta, cull_flags)) != YH_OK) {
+    const double t_up = now_ms();
+    rc = yh_frame(s->scene, s->planes, s->n_frusta, cull_flags); /* returns when the device is done */
+    const double t_frame = now_ms();
+    if (rc != YH_OK) {
         s->n_dirty[0] = s->n_dirty[1] = 0;
         s->status = rc;
         return;
@@ -961,17 +1070,23 @@ static void run(ecs_iter_t* it) {
         s->last_down_rows = 2 * s->n;
         s->host_stale = 0;
     } else {
-        /* every row the frame recomputed or found dirty, flags cleared; all other rows are as flecs holds them */
-        uint64_t m = 0;
-        if ((rc = yh_download_changed_aos68(s->scene, s->slot_buf, s->stage_w, s->stage_l, s->n, &m)) != YH_OK) {
+        /* Every row the frame recomputed or found dirty, flags cleared; all other rows are as flecs holds them.  The two
+         * components come back separately: a parent that moved rewrote every WorldTransform below it and no
+         * LocalTransform, so only the world rows cross PCIe. */
+        uint64_t mw = 0, ml = 0;
+        if ((rc = yh_get_changed_counts(s->scene, &mw, &ml)) != YH_OK || (mw && (rc = fetch_changed(s, 1, mw)) != YH_OK) ||
+            (ml && (rc = fetch_changed(s, 0, ml)) != YH_OK)) {
             s->status = rc;
             return;
         }
-        scatter_changed(s, m);
-        s->last_down_rows = 2 * m;
+        s->last_down_rows = mw + ml;
     }
     s->n_dirty[0] = s->n_dirty[1] = 0;
     if (root_row) root_row[64] = 0; /* PostWorldTransform reaches the root too (single-term query) */
+    s->last_ms[0] = t_inputs - t_begin;
+    s->last_ms[1] = t_up - t_inputs;
+    s->last_ms[2] = t_frame - t_up;
+    s->last_ms[3] = now_ms() - t_frame;
     s->status = YH_OK;
 }
 
@@ -1017,7 +1132,7 @@ ecs_entity_t GpuTransformCullSystem_registerTo(ecs_world_t* world, ecs_entity_t 
     s->readback = 1;
     {
         long cpus = sysconf(_SC_NPROCESSORS_ONLN);
-        s->threads = cpus >= 8 ? 8 : (cpus > 1 ? (int)cpus : 1);
+        s->threads = cpus >= 16 ? 16 : (cpus > 1 ? (int)cpus : 1); /* placing rows is bound by memory latency: helpers overlap the misses */
     }
     for (int k = 0; k < 2; ++k) {
         ecs_observer_desc_t od;
@@ -1210,6 +1325,10 @@ void GpuTransformCullSystem_walkStats(const GpuTransformCullSystem* s, uint64_t*
     if (skipped) *skipped = s ? s->walks_skipped : 0;
 }
 
+void GpuTransformCullSystem_lastTimes(const GpuTransformCullSystem* s, double ms[4]) {
+    for (int i = 0; i < 4; ++i) ms[i] = s ? s->last_ms[i] : 0.0;
+}
+
 void GpuTransformCullSystem_lastTraffic(const GpuTransformCullSystem* s, uint64_t* rows_up, uint64_t* rows_down) {
     if (rows_up) *rows_up = s ? s->last_up_rows : 0;
     if (rows_down) *rows_down = s ? s->last_down_rows : 0;
@@ -1239,6 +1358,7 @@ void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     }
     for (unsigned k = 0; k < sizeof s->observers / sizeof s->observers[0]; ++k)
         if (s->observers[k] && s->world) ecs_delete(s->world, s->observers[k]);
-    free(s->slot_buf);
+    if (s->slot_buf_pinned) yh_host_free(s->ctx, s->slot_buf);
+    else free(s->slot_buf);
     free(s);
 }
