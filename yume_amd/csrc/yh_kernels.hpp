@@ -233,13 +233,15 @@ __device__ __forceinline__ void load_inputs(const FrameArgs& a, uint32_t e, TrsI
 // tile itself (16 per load, v_dot4: at most 64 KiB of L2-resident bytes) — one dependent launch less per frame, and
 // the expansion can ride on the next frame's first launch (4M flat: 86.5 -> 79.1 us; 2048 tiles: worse at 8M).
 #define YH_EXPAND_WORDS_MAX 256
+#define YH_SEG_SHIFT 12  // k_count segment: 4096 words (262 144 entities), a multiple of every tile size
 #define YH_SELF_COUNT_TILES 1024
 
 struct ExpandArgs {
     const uint64_t* vismask;
     const uint8_t* viscnt;  // [frustum][cnt_stride] popcounts of the words, written with them
     uint32_t cnt_stride;
-    uint32_t* tilecnt;      // [frustum][n_tiles]
+    uint32_t* tilecnt;      // [frustum][tc_stride]: per tile, the entries of its 4096-word segment before it; then per segment, its entries (k_count)
+    uint32_t tc_stride;     // n_tiles + segments
     uint32_t* counts;       // device totals [frustum] (input of the RCCL all-gather)
     uint32_t* bcount_cur;   // boundary counters accumulated by this frame's launches
     uint32_t* bcount_next;  // the set of the frame after next: zeroed here (the next frame's launches may be running)
@@ -261,55 +263,117 @@ __device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* s_red) {
     return r;
 }
 
-// Expansion loop of one wave over its run of words (lane i of m_lo / m_hi holds word i, i < n_words): entry j of the
+// Expansion of one wave's run of words (lane i of m_lo / m_hi holds word i, zero past the run's end): entry j of the
 // run's stretch of the list, out[j], is id0 + 64 * i + (bit index) of the j-th set bit.  Written out in ISA because
-// the loop is bound by instruction ISSUE, scalar and vector alike: per word two v_readlane bring the word to the
-// scalar unit, EXEC is narrowed to the word itself (no lane tests its own bit), v_mbcnt gives the rank among the set
-// bits, one v_add_lshl the byte offset from the scalar running position, one v_lshl_add the entity id, and ONE store
-// writes them; s_bcnt1 advances the position.  6 vector + 8 scalar instructions per non-zero word, 2 + 6 per zero
-// word (round 1: 14 vector instructions per word and two LDS reads; a first C++ version of this loop: 6 vector but
-// 19 scalar ones - address arithmetic, EXEC save/restore and the capacity test per word - and the ONE scalar unit of
-// a CU made it slower than before).  Every wave that gets here has all 64 lanes active (whole 256-thread workgroups,
-// wave-uniform exits only), so EXEC is simply set to the word and restored before the block ends; vector stores only.
-__device__ __forceinline__ void expand_run(uint32_t* out /* uniform: the run's first list entry */, uint32_t m_lo, uint32_t m_hi,
-                                           uint32_t n_words /* uniform */, uint32_t id0) {
-    uint64_t saved;
-    uint32_t lo, hi, i, pos, cnt, rank, off, id;
-    // the "s" operands must BE scalar registers (the compiler does not move a value it thinks divergent for us)
-    n_words = __builtin_amdgcn_readfirstlane(n_words);
-    // (readfirstlane returns a signed int: widen each half through uint32_t, or a low half with bit 31 set smears ones
-    // over the high half of the address)
-    const uint64_t o = (uint64_t)(uintptr_t)out;
+// the loop is bound by instruction ISSUE, and by the ONE scalar unit of a CU before the four vector units: per word two
+// v_readlane (lane index an immediate: the sixteen words of a group are unrolled, no counter, compare or branch) bring
+// the word to the scalar unit, EXEC is narrowed to the word itself (no lane tests its own bit; an empty word simply
+// executes nothing), v_mbcnt gives the rank among the set bits, one v_add_lshl the byte offset from the scalar running
+// position, one v_add the entity id, and ONE store writes them; s_bcnt1 advances the position.  6 vector + 4 scalar
+// instructions per word (round 2's first version, a loop: 6 + 8 and a branch, 13.6 cycles per word and CU at cfg3 =
+// the scalar unit's issue rate; round 1: 14 vector instructions per word and two LDS reads).  Every wave that gets
+// here has all 64 lanes active (whole 256-thread workgroups, wave-uniform exits only), so EXEC is simply set to the
+// word and restored before the block ends; vector stores only.
+#define YH_XW(K, STORE)                                 \
+    "v_readlane_b32 %[lo], %[mlo], " #K "\n\t"          \
+    "v_readlane_b32 %[hi], %[mhi], " #K "\n\t"          \
+    "s_nop 0\n\t"                                       \
+    "s_mov_b32 exec_lo, %[lo]\n\t"                      \
+    "s_mov_b32 exec_hi, %[hi]\n\t"                      \
+    "v_mbcnt_lo_u32_b32 %[rank], exec_lo, 0\n\t"        \
+    "v_mbcnt_hi_u32_b32 %[rank], exec_hi, %[rank]\n\t"  \
+    "v_add_u32 %[id], 64*" #K ", %[id0]\n\t"            \
+    "v_add_lshl_u32 %[off], %[rank], %[pos], 2\n\t"     \
+    "s_bcnt1_i32_b64 %[cnt], exec\n\t"                  \
+    STORE "\n\t"                                        \
+    "s_add_u32 %[pos], %[pos], %[cnt]\n\t"
+#define YH_XW16(STORE)                                                                                                 \
+    YH_XW(0, STORE) YH_XW(1, STORE) YH_XW(2, STORE) YH_XW(3, STORE) YH_XW(4, STORE) YH_XW(5, STORE) YH_XW(6, STORE)     \
+    YH_XW(7, STORE) YH_XW(8, STORE) YH_XW(9, STORE) YH_XW(10, STORE) YH_XW(11, STORE) YH_XW(12, STORE) YH_XW(13, STORE) \
+    YH_XW(14, STORE) YH_XW(15, STORE)
+// `out` as a value the compiler knows to be uniform (the "s" operands of the asm must BE scalar registers; readfirstlane
+// returns a signed int: widen each half through uint32_t, or a low half with bit 31 set smears ones over the high half)
+__device__ __forceinline__ uint32_t* uniform_ptr(uint32_t* p) {
+    const uint64_t o = (uint64_t)(uintptr_t)p;
     const uint32_t o_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)o);
     const uint32_t o_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(o >> 32));
-    out = (uint32_t*)(uintptr_t)(((uint64_t)o_hi << 32) | (uint64_t)o_lo);
+    return (uint32_t*)(uintptr_t)(((uint64_t)o_hi << 32) | (uint64_t)o_lo);
+}
+// Sixteen words (lanes 0..15 of the masks) straight to the list; returns the entries written.
+__device__ __forceinline__ uint32_t expand_run16(uint32_t* out /* uniform */, uint32_t m_lo, uint32_t m_hi, uint32_t id0) {
+    uint64_t saved;
+    uint32_t lo, hi, pos, cnt, rank, off, id;
+    out = uniform_ptr(out);
     asm volatile(
         "s_mov_b64 %[saved], exec\n\t"
-        "s_mov_b32 %[i], 0\n\t"
-        "s_mov_b32 %[pos], 0\n"
-        "yh_expand_loop_%=:\n\t"
-        "v_readlane_b32 %[lo], %[mlo], %[i]\n\t"
-        "v_readlane_b32 %[hi], %[mhi], %[i]\n\t"
-        "s_nop 0\n\t"
-        "s_mov_b32 exec_lo, %[lo]\n\t"
-        "s_mov_b32 exec_hi, %[hi]\n\t"
-        "s_cbranch_execz yh_expand_skip_%=\n\t"
-        "v_mbcnt_lo_u32_b32 %[rank], exec_lo, 0\n\t"
-        "v_mbcnt_hi_u32_b32 %[rank], exec_hi, %[rank]\n\t"
-        "v_lshl_add_u32 %[id], %[i], 6, %[id0]\n\t"
-        "v_add_lshl_u32 %[off], %[rank], %[pos], 2\n\t"
-        "s_bcnt1_i32_b64 %[cnt], exec\n\t"
-        "global_store_dword %[off], %[id], %[out]\n\t"
-        "s_add_u32 %[pos], %[pos], %[cnt]\n"
-        "yh_expand_skip_%=:\n\t"
-        "s_add_u32 %[i], %[i], 1\n\t"
-        "s_cmp_lt_u32 %[i], %[n]\n\t"
-        "s_cbranch_scc1 yh_expand_loop_%=\n\t"
+        "s_mov_b32 %[pos], 0\n\t"
+        YH_XW16("global_store_dword %[off], %[id], %[out]")
         "s_mov_b64 exec, %[saved]"
-        : [saved] "=&s"(saved), [lo] "=&s"(lo), [hi] "=&s"(hi), [i] "=&s"(i), [pos] "=&s"(pos), [cnt] "=&s"(cnt),
+        : [saved] "=&s"(saved), [lo] "=&s"(lo), [hi] "=&s"(hi), [pos] "=&s"(pos), [cnt] "=&s"(cnt),
           [rank] "=&v"(rank), [off] "=&v"(off), [id] "=&v"(id)
-        : [mlo] "v"(m_lo), [mhi] "v"(m_hi), [n] "s"(n_words), [id0] "v"(id0), [out] "s"(out)
+        : [mlo] "v"(m_lo), [mhi] "v"(m_hi), [id0] "v"(id0), [out] "s"(out)
         : "memory", "scc");
+    return pos;
+}
+// The same sixteen words through LDS: a word's store above writes popcount(word) entries wherever the list has got to,
+// 166 bytes on average at cfg5 and across two or three 128-byte lines; here the entries of the sixteen words are
+// compacted into the wave's own LDS rows first, laid out as the list is relative to the 256-byte boundary below `out`,
+// and go out as whole aligned 256-byte rows (the first and the last one partial).  MEASURED SLOWER and kept as an
+// experiment build only (profiles/r02/ab_expand.txt: expansion stage cfg3 48.1 vs 39.5 us, cfg4 22.9 vs 18.3, cfg5
+// 156 vs 154): the stores were not what held the direct version back.
+#define YH_STAGE_ENTRIES (16 * 64 + 64)
+__device__ __forceinline__ uint32_t expand_run16_lds(uint32_t* out /* uniform */, uint32_t m_lo, uint32_t m_hi, uint32_t id0,
+                                                     uint32_t* stage /* this wave's YH_STAGE_ENTRIES words of LDS */) {
+    uint64_t saved;
+    uint32_t lo, hi, cnt, rank, off, id;
+    out = uniform_ptr(out);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t a = ((uint32_t)(uintptr_t)out >> 2) & 63u;  // list entries between that boundary and `out`
+    // (the low half of an LDS variable's generic address is its LDS byte offset)
+    const uint32_t pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((((uint32_t)(uintptr_t)stage) >> 2) + a);
+    uint32_t pos = pos0;
+    asm volatile(
+        "s_mov_b64 %[saved], exec\n\t"
+        YH_XW16("ds_write_b32 %[off], %[id]")
+        "s_mov_b64 exec, %[saved]\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [saved] "=&s"(saved), [lo] "=&s"(lo), [hi] "=&s"(hi), [pos] "+s"(pos), [cnt] "=&s"(cnt),
+          [rank] "=&v"(rank), [off] "=&v"(off), [id] "=&v"(id)
+        : [mlo] "v"(m_lo), [mhi] "v"(m_hi), [id0] "v"(id0)
+        : "memory", "scc");
+    const uint32_t written = pos - pos0, total = a + written;
+    uint32_t* __restrict__ row0 = out - a;
+    for (uint32_t r = 0; r < total; r += 64u) {
+        const uint32_t i = r + lane;
+        if (i >= a && i < total) row0[i] = stage[i];
+    }
+    return written;
+}
+#undef YH_XW16
+#undef YH_XW
+#if defined(YH_EXPAND_LDS)  // experiment build (tools/ab_expand.sh): rows staged in LDS
+#define YH_EXPAND_STAGE_WORDS YH_STAGE_ENTRIES
+#else
+#define YH_EXPAND_STAGE_WORDS 1
+#endif
+// A run of n_words <= 64 words: groups of sixteen, the masks rotated down by sixteen lanes between groups.
+__device__ __forceinline__ void expand_run(uint32_t* out /* uniform: the run's first list entry */, uint32_t m_lo, uint32_t m_hi,
+                                           uint32_t n_words /* uniform */, uint32_t id0, uint32_t* stage) {
+    const uint32_t src = (((threadIdx.x & 63u) + 16u) & 63u) << 2;
+    n_words = __builtin_amdgcn_readfirstlane(n_words);
+    for (uint32_t g = 0;;) {
+#if defined(YH_EXPAND_LDS)
+        const uint32_t written = expand_run16_lds(out, m_lo, m_hi, id0, stage);
+#else
+        const uint32_t written = expand_run16(out, m_lo, m_hi, id0);
+#endif
+        g += 16u;
+        if (g >= n_words) break;
+        out += written;
+        id0 += 16u * 64u;
+        m_lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)m_lo);
+        m_hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)m_hi);
+    }
 }
 
 // Expansion of one tile of visibility words into its stretch of the ordered list.  Every wave owns a CONTIGUOUS run of
@@ -318,6 +382,7 @@ __device__ __forceinline__ void expand_run(uint32_t* out /* uniform: the run's f
 __device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t t, const uint32_t f) {
     __shared__ uint32_t s_red[4];
     __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_stage[4][YH_EXPAND_STAGE_WORDS];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t* __restrict__ masks = x.vismask + (uint64_t)f * x.n_chunks;
@@ -336,11 +401,12 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t 
             part = __builtin_amdgcn_udot4(v.z, 0x01010101u, part, false);
             part = __builtin_amdgcn_udot4(v.w, 0x01010101u, part, false);
         }
-    } else {
-        const uint32_t* __restrict__ cnt = x.tilecnt + (uint64_t)f * x.n_tiles;
-        for (uint32_t i = tid; i < t; i += YH_BLOCK) part += cnt[i];
+    } else {  // k_count left: per tile its segment's entries before it, per segment its entries (a few hundred at most)
+        const uint32_t* __restrict__ seg = x.tilecnt + (uint64_t)f * x.tc_stride + x.n_tiles;
+        for (uint32_t i = tid; i < (c0 >> YH_SEG_SHIFT); i += YH_BLOCK) part += seg[i];
     }
-    const uint32_t base = block_sum_256(part, s_red);
+    uint32_t base = block_sum_256(part, s_red);
+    if (!x.self_count) base += x.tilecnt[(uint64_t)f * x.tc_stride + t];
     // visible entities of each wave's run
     uint32_t run = (uint32_t)__popcll(m);
 #pragma unroll
@@ -370,7 +436,7 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t 
     const uint32_t cap = x.draw_cap > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)x.draw_cap;
     if (n_words == 0) return;
     if (pos + run <= cap) {  // the whole run fits the list: the issue-lean loop
-        expand_run(out + pos, m_lo, m_hi, n_words, id0);
+        expand_run(out + pos, m_lo, m_hi, n_words, id0, s_stage[wv]);
         return;
     }
     for (uint32_t i = 0; i < n_words; ++i) {  // the list overflows inside this run: every lane checks its own entry
@@ -764,13 +830,41 @@ __global__ __launch_bounds__(YH_BLOCK) void k_chain_mat4(const FrameArgs a, cons
     if (BOUNDS != 0) publish_visible(a, (uint32_t)(e64 >> 6), e64 - (tid & 63u) < a.begin, vmask, bmask);
 }
 
+// Tile bases of the expansion, from the popcount BYTES the frame kernels left next to the words: one workgroup per
+// segment of 4096 words (16 bytes = one load per thread), grid = (segments, frusta).  Writes, per tile, the entries of
+// its segment before it, and per segment its entries: an expand workgroup then adds up the segments before its own (at
+// most a few hundred values even at 256M entities) instead of every tile before its own (round 2's first version:
+// 15 625 tiles at 256M entities, 31 KB read per workgroup, more time than the expansion itself).
 __global__ __launch_bounds__(YH_BLOCK) void k_count(const ExpandArgs x) {
-    __shared__ uint32_t s_red[4];
-    const uint32_t t = blockIdx.x, f = blockIdx.y;
-    const uint32_t c = t * x.words + threadIdx.x;
-    const uint64_t m = (threadIdx.x < x.words && c < x.n_chunks) ? x.vismask[(uint64_t)f * x.n_chunks + c] : 0ull;
-    const uint32_t total = block_sum_256((uint32_t)__popcll(m), s_red);
-    if (threadIdx.x == 0) x.tilecnt[f * x.n_tiles + t] = total;
+    __shared__ uint32_t s_w[4];
+    const uint32_t seg = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t w0 = (seg << YH_SEG_SHIFT) + tid * 16u;  // first word of this thread's 16 count bytes
+    uint32_t c = 0;
+    if (w0 < x.n_chunks) {
+        const uint4 v = *reinterpret_cast<const uint4*>(x.viscnt + (uint64_t)f * x.cnt_stride + w0);
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t valid = x.n_chunks - w0;  // bytes past the last word are padding: whatever was there
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t nb = valid > 4u * q ? valid - 4u * q : 0u;
+            const uint32_t keep = nb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
+            c = __builtin_amdgcn_udot4(d[q] & keep, 0x01010101u, c, false);
+        }
+    }
+    uint32_t inc = c;  // inclusive scan over the wave, then over the four waves
+#pragma unroll
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63u) s_w[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wv; ++w) before += s_w[w];
+    const uint32_t excl = before + inc - c;  // entries of this segment before this thread's words
+    uint32_t* __restrict__ row = x.tilecnt + (uint64_t)f * x.tc_stride;
+    if (w0 < x.n_chunks && w0 % x.words == 0) row[w0 / x.words] = excl;  // x.words is 32, 64 or 256: a tile starts at a thread
+    if (tid == YH_BLOCK - 1) row[x.n_tiles + seg] = excl + c;
 }
 
 __global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) { expand_tile(x, blockIdx.x, blockIdx.y); }
@@ -944,6 +1038,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_gather_count(const GatherArgs g) {
 __global__ __launch_bounds__(YH_BLOCK) void k_gather_expand(const GatherArgs g) {
     __shared__ uint32_t s_red[4];
     __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_stage[4][YH_EXPAND_STAGE_WORDS];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t t = blockIdx.x, f = blockIdx.y, r = blockIdx.z;
@@ -970,7 +1065,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_gather_expand(const GatherArgs g) 
     const uint32_t n_words = min(wpw, g.words > cw ? g.words - cw : 0u);
     if (n_words == 0) return;
     const uint32_t pos = __builtin_amdgcn_readfirstlane(base + before);
-    expand_run(g.out[f] + pos, (uint32_t)m, (uint32_t)(m >> 32), n_words, (cw << 6) + lane + g.peer[r * 4 + 1]);
+    expand_run(g.out[f] + pos, (uint32_t)m, (uint32_t)(m >> 32), n_words, (cw << 6) + lane + g.peer[r * 4 + 1], s_stage[wv]);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -77,6 +77,7 @@ struct yh_scene {
     uint8_t* chg_cnt = nullptr;       // the same for the change mask
     uint64_t vis_bytes = 0;           // bytes of the counts allocation (zeroed once at creation)
     uint32_t n_chunks = 0, n_tiles = 0, tile_words = 64;
+    uint32_t n_segs = 0;              // k_count segments (4096 words each); tile-count rows hold n_tiles + n_segs words
     uint32_t* h_counts = nullptr;     // host-mapped: written by k_expand ([f] totals, [8+f] boundary counts)
     uint32_t* h_counts_dev = nullptr; // device address of h_counts
     uint32_t bset = 0;                // which of the three boundary-counter sets this frame uses
@@ -395,9 +396,14 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
     s->tile_words = s->n_chunks <= 32u * 512u ? 32u
                     : s->n_chunks <= 32u * 4096u                       ? 64u
                                                                        : (uint32_t)YH_EXPAND_WORDS_MAX;
+    if (const char* v = getenv("YH_TILE_WORDS")) {  // A/B of the expand tile size (tools/ab_tile_words.sh): 32, 64 or 256
+        const uint32_t w = (uint32_t)strtoul(v, nullptr, 10);
+        if (w == 32u || w == 64u || w == 256u) s->tile_words = w;
+    }
     s->n_tiles = (s->n_chunks + s->tile_words - 1) / s->tile_words;
     const uint64_t F_alloc = d->n_frusta ? d->n_frusta : 1;
-    const uint64_t tile_words = (F_alloc * s->n_tiles + 1) & ~1ull;
+    s->n_segs = (s->n_chunks + (1u << YH_SEG_SHIFT) - 1) >> YH_SEG_SHIFT;
+    const uint64_t tile_words = (F_alloc * (s->n_tiles + s->n_segs) + 1) & ~1ull;
     s->cnt_stride = (s->n_chunks + 15u) & ~15u;
     s->vis_bytes = (4 * YH_MAX_FRUSTA + tile_words) * 4 + F_alloc * s->n_chunks * 8 + F_alloc * s->cnt_stride + 16;
     alloc((void**)&s->counts, s->vis_bytes);
@@ -833,7 +839,7 @@ extern "C" int yh_scene_track_changes(yh_scene* s, int enable) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc = sync_scene(s)) return rc;
     if (enable && !s->chg) {
-        const uint64_t tile_words = ((uint64_t)s->n_tiles + 1) & ~1ull;
+        const uint64_t tile_words = ((uint64_t)s->n_tiles + s->n_segs + 1) & ~1ull;
         // two masks (k_sweep_dirty), laid out as two frusta of a visibility set: [mask][n_tiles | n_chunks | cnt_stride]
         const uint64_t bytes = (32 + 2 * tile_words) * 4 + 2 * (uint64_t)s->n_chunks * 8 + 2 * (uint64_t)s->cnt_stride + 16;
         HIP_TRY(ctx, hipMalloc((void**)&s->chg, bytes));
@@ -1175,7 +1181,7 @@ static StaticLayout static_layout(const yh_scene* s, uint32_t n_frusta) {
     const uint64_t F = n_frusta ? n_frusta : 1;
     StaticLayout l;
     l.tilecnt_off = 4 * YH_MAX_FRUSTA * 4;
-    l.words_off = l.tilecnt_off + ((F * s->n_tiles + 1) & ~1ull) * 4;
+    l.words_off = l.tilecnt_off + ((F * (s->n_tiles + s->n_segs) + 1) & ~1ull) * 4;
     l.cnt_off = (l.words_off + F * s->n_chunks * 8 + 15) & ~15ull;
     l.bytes = l.cnt_off + F * s->cnt_stride;
     return l;
@@ -1401,6 +1407,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
             c.viscnt = s->chg_cnt;
             c.cnt_stride = s->cnt_stride;
             c.tilecnt = s->chg_tilecnt;
+            c.tc_stride = (uint32_t)(((uint64_t)s->n_tiles + s->n_segs + 1) & ~1ull);
             c.counts = s->chg;
             c.bcount_cur = s->chg + YH_MAX_FRUSTA;
             c.bcount_next = s->chg + 2 * YH_MAX_FRUSTA;
@@ -1412,7 +1419,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
             c.n_tiles = s->n_tiles;
             c.words = s->tile_words;
             c.self_count = (s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES && s->tile_words <= 64u);
-            if (!c.self_count) hipLaunchKernelGGL(k_count, dim3(s->n_tiles, 2), dim3(YH_BLOCK), 0, st, c);
+            if (!c.self_count) hipLaunchKernelGGL(k_count, dim3(s->n_segs, 2), dim3(YH_BLOCK), 0, st, c);
             hipLaunchKernelGGL(k_expand, dim3(s->n_tiles, 2), dim3(YH_BLOCK), 0, st, c);
             HIP_TRY(ctx, hipGetLastError());
             s->chg_valid = true;
@@ -1454,12 +1461,13 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
         x.draw_cap = s->draw_cap;
         x.n_chunks = s->n_chunks;
         x.n_tiles = s->n_tiles;
+        x.tc_stride = s->n_tiles + s->n_segs;
         x.words = s->tile_words;
         x.id_base = s->desc.id_base;
         x.self_count = (s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES && s->tile_words <= 64u);
         if (int rc = time_begin(YH_MAX_LEVELS - 1)) return rc;
         if (!x.self_count) {
-            hipLaunchKernelGGL(k_count, dim3(s->n_tiles, n_frusta), dim3(YH_BLOCK), 0, st, x);
+            hipLaunchKernelGGL(k_count, dim3(s->n_segs, n_frusta), dim3(YH_BLOCK), 0, st, x);
             HIP_TRY(ctx, hipGetLastError());
             ++launches;
         }
