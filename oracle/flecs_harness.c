@@ -345,9 +345,9 @@ int main(int argc, char** argv) {
         {
             fprintf(stderr, "frame %u: %.3f ms, %u edits\n", f, (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, n_edits);
 #ifdef USE_GPU_SYSTEM
-            double st[4];
+            double st[6];
             GpuTransformCullSystem_lastTimes(gpu, st);
-            fprintf(stderr, "stages %u: inputs %.3f up %.3f frame %.3f down %.3f\n", f, st[0], st[1], st[2], st[3]);
+            fprintf(stderr, "stages %u: inputs %.3f (walk %.3f, rebuild %.3f) up %.3f frame %.3f down %.3f\n", f, st[0], st[4], st[5], st[1], st[2], st[3]);
 #endif
         }
         for (int comp = 0; comp < 2; ++comp) {

@@ -1,6 +1,7 @@
 """End-to-end frame time inside the REAL flecs (oracle/_ref harnesses): the reference's CPU systems against the GPU
 system, whole-column and incremental modes.  usage: python tools/flecs_bench.py [n] [levels]
-Frames: 0 everything dirty (first frame), 1 nothing dirty, 2 1 % local edits, 3 nothing dirty, 4 root moved, 5 nothing dirty."""
+Frames: 0 everything dirty (first frame), 1 nothing dirty, 2 1 % local edits, 3 nothing dirty, 4 root moved, 5 nothing dirty,
+6 one leaf re-parented (structural change, same entity count), 7 nothing dirty, 8 that leaf deleted (entity count changes), 9 nothing dirty."""
 import os
 import subprocess
 import sys
@@ -23,7 +24,12 @@ bounds = oracle.synth_aabb(n)
 planes = oracle.main_camera_planes().reshape(1, 24)
 m = oracle.compose([1, 2, 3], [0, 0, 0, 1], [1, 1, 1])
 edits = [(int(e), 0, m) for e in np.unique(rng.integers(0, n, n // 100))]
+leaf = n - 1  # a last-level entity: frame 6 moves it under another parent (same entity count), frame 8 deletes it
+new_parent = int(lo[-3]) if levels > 1 else 0
 frames = [[], [], edits, [], [(-1, 1, oracle.compose([1, 2, 3], [0, 0.7071068, 0, 0.7071068], [2, 2, 2]))], []]
+if levels > 2:
+    from tests.test_gpu_flecs_system import reparent_arg
+    frames += [[(leaf, 3, reparent_arg(new_parent))], [], [(leaf, 2, np.zeros(16, np.float32))], []]
 with tempfile.TemporaryDirectory() as d:
     scene = os.path.join(d, "scene.bin")
     write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)

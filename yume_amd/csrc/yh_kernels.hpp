@@ -250,6 +250,7 @@ struct ExpandArgs {
     uint64_t draw_cap;
     uint32_t n_chunks, n_tiles, id_base, self_count;
     uint32_t words;  // visibility words per tile: 32, 64 or 256
+    uint32_t tiles_per_wg; // k_expand: consecutive tiles one workgroup expands (>= 1)
     uint32_t fuse_blocks;  // k_frame_*_x: the launch's first fuse_blocks workgroups expand these (the previous frame's) words
 };
 
@@ -376,21 +377,25 @@ __device__ __forceinline__ void expand_run(uint32_t* out /* uniform: the run's f
     }
 }
 
-// Expansion of one tile of visibility words into its stretch of the ordered list.  Every wave owns a CONTIGUOUS run of
-// the tile's words: lane l loads word l of the run (one coalesced load), the run's words then come back one at a time
-// as wave-uniform values (v_readlane), so the running output position lives on the scalar unit (expand_run).
-__device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t t, const uint32_t f) {
+// Expansion of tiles [t0, t1) of visibility words into their stretch of the ordered list.  Every wave owns a CONTIGUOUS
+// run of a tile's words: lane l loads word l of the run (one coalesced load), the run's words then come back one at a
+// time as wave-uniform values (v_readlane), so the running output position lives on the scalar unit (expand_run).
+// Larger tiles are faster (profiles/r02/ab_tile_words.txt: the stage's time is ~1.3 ns x workgroups + the time of the
+// words), which suggested giving a workgroup several consecutive tiles - the base carried from tile to tile, the next
+// tile's words loaded before this tile's are expanded.  The loop is here and tested, the host asks for ONE tile: two
+// to sixteen measured equal or slower at every size (profiles/r02/ab_expand_tiles_per_wg.txt).
+__device__ __forceinline__ void expand_tiles(const ExpandArgs& x, const uint32_t t0, const uint32_t t1, const uint32_t f) {
     __shared__ uint32_t s_red[4];
-    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_wave[2][4];
     __shared__ uint32_t s_stage[4][YH_EXPAND_STAGE_WORDS];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t* __restrict__ masks = x.vismask + (uint64_t)f * x.n_chunks;
-    const uint32_t c0 = t * x.words;
+    const uint32_t c0 = t0 * x.words;
     const uint32_t wpw = x.words >> 2;      // words per wave: 8, 16 or 64
-    const uint32_t cw = c0 + wv * wpw;      // first word of this wave's run
-    const uint64_t m = (lane < wpw && cw + lane < x.n_chunks) ? masks[cw + lane] : 0ull;
-    // base = visible entities in the tiles before this one
+    uint32_t cw = c0 + wv * wpw;            // first word of this wave's run
+    uint64_t m = (lane < wpw && cw + lane < x.n_chunks) ? masks[cw + lane] : 0ull;
+    // base = visible entities in the tiles before the first one
     uint32_t part = 0;
     if (x.self_count) {  // 16 byte-counts per load; c0 is a multiple of 32
         const uint4* __restrict__ c16 = reinterpret_cast<const uint4*>(x.viscnt + (uint64_t)f * x.cnt_stride);
@@ -406,47 +411,56 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t 
         for (uint32_t i = tid; i < (c0 >> YH_SEG_SHIFT); i += YH_BLOCK) part += seg[i];
     }
     uint32_t base = block_sum_256(part, s_red);
-    if (!x.self_count) base += x.tilecnt[(uint64_t)f * x.tc_stride + t];
-    // visible entities of each wave's run
-    uint32_t run = (uint32_t)__popcll(m);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) run += __shfl_xor(run, o);
-    run = __builtin_amdgcn_readfirstlane(run);  // the same in every lane: say so, the branches below are then scalar
-    if (lane == 0) s_wave[wv] = run;
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < wv; ++w) before += s_wave[w];
-    const uint32_t own = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    if (tid == 0) {
-        if (t == 0 && f == 0)  // all of them: the frame that uses this set next may cull more frusta than this one
-            for (uint32_t q = 0; q < YH_K_MAX_FRUSTA; ++q) x.bcount_next[q] = 0;
-        if (t + 1 == x.n_tiles) {  // totals of this frustum, to the device (all-gather) and straight to the host
-            x.counts[f] = base + own;
-            x.host_counts[f] = base + own;
-            x.host_counts[YH_K_MAX_FRUSTA + f] = x.bcount_cur[f];
-        }
-    }
-    if (run == 0) return;  // (wave-uniform after the reduction)
-    uint32_t* __restrict__ out = x.draw[f];
-    uint32_t pos = __builtin_amdgcn_readfirstlane(base + before);  // scalar: list position of the run's next entry
-    const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
-    const uint32_t id0 = (cw << 6) + lane + x.id_base;
-    const uint32_t n_words = min(wpw, x.n_chunks > cw ? x.n_chunks - cw : 0u);
+    if (!x.self_count) base += x.tilecnt[(uint64_t)f * x.tc_stride + t0];
     // (entity counts stay below 2^31: positions and the capacity compare in 32 bits)
     const uint32_t cap = x.draw_cap > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)x.draw_cap;
-    if (n_words == 0) return;
-    if (pos + run <= cap) {  // the whole run fits the list: the issue-lean loop
-        expand_run(out + pos, m_lo, m_hi, n_words, id0, s_stage[wv]);
-        return;
-    }
-    for (uint32_t i = 0; i < n_words; ++i) {  // the list overflows inside this run: every lane checks its own entry
-        const uint32_t lo = __builtin_amdgcn_readlane(m_lo, i), hi = __builtin_amdgcn_readlane(m_hi, i);
-        const uint64_t word = ((uint64_t)hi << 32) | lo;
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-        if (((word >> lane) & 1ull) && pos + rank < cap) out[pos + rank] = id0 + (i << 6);
-        pos += (uint32_t)__popcll(word);
+    uint32_t* __restrict__ out = x.draw[f];
+    for (uint32_t t = t0; t < t1; ++t, cw += x.words) {
+        // the next tile's words, on their way while this tile is expanded
+        const uint32_t cn = cw + x.words;
+        const uint64_t m_next = (t + 1 < t1 && lane < wpw && cn + lane < x.n_chunks) ? masks[cn + lane] : 0ull;
+        // visible entities of each wave's run
+        uint32_t run = (uint32_t)__popcll(m);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) run += __shfl_xor(run, o);
+        run = __builtin_amdgcn_readfirstlane(run);  // the same in every lane: say so, the branches below are then scalar
+        uint32_t* sw = s_wave[(t - t0) & 1u];  // two sets: a wave may write tile t + 1's while another still reads tile t's
+        if (lane == 0) sw[wv] = run;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wv; ++w) before += sw[w];
+        const uint32_t own = sw[0] + sw[1] + sw[2] + sw[3];
+        if (tid == 0) {
+            if (t == 0 && f == 0)  // all of them: the frame that uses this set next may cull more frusta than this one
+                for (uint32_t q = 0; q < YH_K_MAX_FRUSTA; ++q) x.bcount_next[q] = 0;
+            if (t + 1 == x.n_tiles) {  // totals of this frustum, to the device (all-gather) and straight to the host
+                x.counts[f] = base + own;
+                x.host_counts[f] = base + own;
+                x.host_counts[YH_K_MAX_FRUSTA + f] = x.bcount_cur[f];
+            }
+        }
+        const uint32_t n_words = min(wpw, x.n_chunks > cw ? x.n_chunks - cw : 0u);
+        if (run != 0 && n_words != 0) {  // (wave-uniform after the reduction)
+            uint32_t pos = __builtin_amdgcn_readfirstlane(base + before);  // scalar: list position of the run's next entry
+            const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
+            const uint32_t id0 = (cw << 6) + lane + x.id_base;
+            if (pos + run <= cap) {  // the whole run fits the list: the issue-lean loop
+                expand_run(out + pos, m_lo, m_hi, n_words, id0, s_stage[wv]);
+            } else {
+                for (uint32_t i = 0; i < n_words; ++i) {  // the list overflows inside this run: every lane checks its own entry
+                    const uint32_t lo = __builtin_amdgcn_readlane(m_lo, i), hi = __builtin_amdgcn_readlane(m_hi, i);
+                    const uint64_t word = ((uint64_t)hi << 32) | lo;
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+                    if (((word >> lane) & 1ull) && pos + rank < cap) out[pos + rank] = id0 + (i << 6);
+                    pos += (uint32_t)__popcll(word);
+                }
+            }
+        }
+        base += own;
+        m = m_next;
     }
 }
+__device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t t, const uint32_t f) { expand_tiles(x, t, t + 1u, f); }
 
 
 // ---------------------------------------------------------------------------------------------------
@@ -867,7 +881,11 @@ __global__ __launch_bounds__(YH_BLOCK) void k_count(const ExpandArgs x) {
     if (tid == YH_BLOCK - 1) row[x.n_tiles + seg] = excl + c;
 }
 
-__global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) { expand_tile(x, blockIdx.x, blockIdx.y); }
+// grid = (ceil(n_tiles / tiles_per_wg), frusta)
+__global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) {
+    const uint32_t t0 = blockIdx.x * x.tiles_per_wg;
+    expand_tiles(x, t0, min(t0 + x.tiles_per_wg, x.n_tiles), blockIdx.y);
+}
 
 // The same sweep when changes are tracked (yh_scene_track_changes): one wave per 64-entity chunk first publishes two
 // ballots as the chunk's words of the two change masks, then clears both flags.

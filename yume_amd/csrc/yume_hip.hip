@@ -77,6 +77,7 @@ struct yh_scene {
     uint8_t* chg_cnt = nullptr;       // the same for the change mask
     uint64_t vis_bytes = 0;           // bytes of the counts allocation (zeroed once at creation)
     uint32_t n_chunks = 0, n_tiles = 0, tile_words = 64;
+    uint32_t expand_tiles = 0;        // 0: expand_tiles_per_wg decides
     uint32_t n_segs = 0;              // k_count segments (4096 words each); tile-count rows hold n_tiles + n_segs words
     uint32_t* h_counts = nullptr;     // host-mapped: written by k_expand ([f] totals, [8+f] boundary counts)
     uint32_t* h_counts_dev = nullptr; // device address of h_counts
@@ -454,6 +455,7 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
     if (const char* v = getenv("YH_LDS_PARENTS")) s->lds_parents = v[0] == '1';
     if (const char* v = getenv("YH_BIG_TREE")) s->big_tree = strtoull(v, nullptr, 10);
     if (const char* v = getenv("YH_BIG_FLAT")) s->big_flat = strtoull(v, nullptr, 10);
+    if (const char* v = getenv("YH_EXPAND_TILES")) s->expand_tiles = (uint32_t)strtoul(v, nullptr, 10);
     ctx->scenes.push_back(s);
     *out = s;
     return YH_OK;
@@ -472,7 +474,7 @@ static int check_range(yh_scene* s, const char* who, uint64_t first, uint64_t co
 static int flush_expand(yh_scene* s) {
     if (!s->exp_pending) return YH_OK;
     s->exp_pending = false;
-    hipLaunchKernelGGL(k_expand, dim3(s->pend.n_tiles, s->pend_frusta), dim3(YH_BLOCK), 0, s->ctx->stream, s->pend);
+    hipLaunchKernelGGL(k_expand, dim3(cdiv(s->pend.n_tiles, s->pend.tiles_per_wg), s->pend_frusta), dim3(YH_BLOCK), 0, s->ctx->stream, s->pend);
     HIP_TRY(s->ctx, hipGetLastError());
     return YH_OK;
 }
@@ -1172,6 +1174,11 @@ static void build_cull_plan(const float* planes, uint32_t n_frusta, CullPlan& pl
     plan.n_normals = n_groups;
 }
 
+// Consecutive tiles one k_expand workgroup takes (base carried from tile to tile, the next tile's words loaded ahead).
+// One: more did not pay at any size (profiles/r02/ab_expand_tiles_per_wg.txt: cfg3's stage 41.6 / 39.3 / 42.3 / 49.5 us
+// with 1 / 2 / 4 / 8 tiles, cfg5's 157 / 159 / 168 / 173, cfg4's 18.6 / 20.0 / 26.8 / 38.7).  A/B: env YH_EXPAND_TILES.
+static uint32_t expand_tiles_per_wg(const yh_scene* s, uint32_t) { return s->expand_tiles ? s->expand_tiles : 1u; }
+
 // Where the stage-3 scratch of one frame lies inside the static array (yh_frame_static): 32 counter words (only
 // [8, 24) are used: the boundary counters and the set k_expand zeroes), tile counts, visibility words, byte counts.
 struct StaticLayout {
@@ -1420,7 +1427,8 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
             c.words = s->tile_words;
             c.self_count = (s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES && s->tile_words <= 64u);
             if (!c.self_count) hipLaunchKernelGGL(k_count, dim3(s->n_segs, 2), dim3(YH_BLOCK), 0, st, c);
-            hipLaunchKernelGGL(k_expand, dim3(s->n_tiles, 2), dim3(YH_BLOCK), 0, st, c);
+            c.tiles_per_wg = expand_tiles_per_wg(s, 2);
+            hipLaunchKernelGGL(k_expand, dim3(cdiv(s->n_tiles, c.tiles_per_wg), 2), dim3(YH_BLOCK), 0, st, c);
             HIP_TRY(ctx, hipGetLastError());
             s->chg_valid = true;
             launches += c.self_count ? 2 : 3;
@@ -1465,6 +1473,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
         x.words = s->tile_words;
         x.id_base = s->desc.id_base;
         x.self_count = (s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES && s->tile_words <= 64u);
+        x.tiles_per_wg = expand_tiles_per_wg(s, n_frusta);
         if (int rc = time_begin(YH_MAX_LEVELS - 1)) return rc;
         if (!x.self_count) {
             hipLaunchKernelGGL(k_count, dim3(s->n_segs, n_frusta), dim3(YH_BLOCK), 0, st, x);
@@ -1484,7 +1493,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
             s->pend_frusta = n_frusta;
             s->exp_pending = true;
         } else {
-            hipLaunchKernelGGL(k_expand, dim3(s->n_tiles, n_frusta), dim3(YH_BLOCK), 0, st, x);
+            hipLaunchKernelGGL(k_expand, dim3(cdiv(s->n_tiles, x.tiles_per_wg), n_frusta), dim3(YH_BLOCK), 0, st, x);
             HIP_TRY(ctx, hipGetLastError());
             ++launches;
         }

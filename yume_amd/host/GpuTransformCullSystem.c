@@ -135,7 +135,7 @@ struct GpuTransformCullSystem {
     int slot_buf_pinned;
     ecs_entity_t observers[7];
     uint64_t last_up_rows, last_down_rows;
-    double last_ms[4];       /* the last frame's wall time: tables + inputs, rows up, device frame, rows down and placed */
+    double last_ms[6];       /* the last frame's wall time: tables + inputs, rows up, device frame, rows down and placed; of the first: query walk, slot-order rebuild */
 
     int status;
     uint64_t rebuilds;
@@ -923,7 +923,7 @@ static void run(ecs_iter_t* it) {
     GpuTransformCullSystem* s = (GpuTransformCullSystem*)it->ctx;
     int rc = YH_OK;
     const double t_begin = now_ms();
-    s->last_ms[0] = s->last_ms[1] = s->last_ms[2] = s->last_ms[3] = 0.0;
+    memset(s->last_ms, 0, sizeof s->last_ms);
     int rebuilt = 0;
     /* Nothing structural happened since the batches were last brought up to date (no observer fired, the query's cache
      * matched or unmatched no table): they still are the world's tables, row for row.  No iteration, no validation. */
@@ -941,6 +941,7 @@ static void run(ecs_iter_t* it) {
             ecs_iter_fini(it);
         } else {
             rc = walk(s, it);
+            s->last_ms[4] = now_ms() - t_begin;
             if (rc != YH_OK || s->n == 0) {
                 s->status = rc;
                 return;
@@ -954,7 +955,10 @@ static void run(ecs_iter_t* it) {
                 s->status = rc;
                 return;
             }
-            if ((rc = rebuild(s)) != YH_OK) {
+            const double t_rebuild = now_ms();
+            rc = rebuild(s);
+            s->last_ms[5] = now_ms() - t_rebuild;
+            if (rc != YH_OK) {
                 s->status = rc;
                 return;
             }
@@ -1325,8 +1329,8 @@ void GpuTransformCullSystem_walkStats(const GpuTransformCullSystem* s, uint64_t*
     if (skipped) *skipped = s ? s->walks_skipped : 0;
 }
 
-void GpuTransformCullSystem_lastTimes(const GpuTransformCullSystem* s, double ms[4]) {
-    for (int i = 0; i < 4; ++i) ms[i] = s ? s->last_ms[i] : 0.0;
+void GpuTransformCullSystem_lastTimes(const GpuTransformCullSystem* s, double ms[6]) {
+    for (int i = 0; i < 6; ++i) ms[i] = s ? s->last_ms[i] : 0.0;
 }
 
 void GpuTransformCullSystem_lastTraffic(const GpuTransformCullSystem* s, uint64_t* rows_up, uint64_t* rows_down) {

@@ -106,8 +106,9 @@ int GpuTransformCullSystem_fetchWorld(GpuTransformCullSystem* s, ecs_entity_t en
 int GpuTransformCullSystem_setThreads(GpuTransformCullSystem* s, int n);
 /* 68-byte rows that crossed PCIe in the last frame, each direction (both components counted). */
 /* Wall time of the last frame by stage, ms: [0] tables, root, bounds, frusta; [1] changed rows gathered and sent up;
- * [2] the device frame (yh_frame + wait); [3] changed rows brought down and placed in their tables. */
-void GpuTransformCullSystem_lastTimes(const GpuTransformCullSystem* s, double ms[4]);
+ * [2] the device frame (yh_frame + wait); [3] changed rows brought down and placed in their tables; and, both inside
+ * [0] and zero in a frame without structural change: [4] the walk of the query, [5] the rebuild of the slot order. */
+void GpuTransformCullSystem_lastTimes(const GpuTransformCullSystem* s, double ms[6]);
 void GpuTransformCullSystem_lastTraffic(const GpuTransformCullSystem* s, uint64_t* rows_up, uint64_t* rows_down);
 
 void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s);

@@ -48,7 +48,7 @@ extern fn GpuTransformCullSystem_fetchWorld(s: *State, entity: c.ecs_entity_t, m
 extern fn GpuTransformCullSystem_setThreads(s: *State, n: c_int) c_int;
 extern fn GpuTransformCullSystem_cleanFrames(s: *const State) u64;
 extern fn GpuTransformCullSystem_walkStats(s: *const State, walks: ?*u64, skipped: ?*u64) void;
-extern fn GpuTransformCullSystem_lastTimes(s: *const State, ms: *[4]f64) void;
+extern fn GpuTransformCullSystem_lastTimes(s: *const State, ms: *[6]f64) void;
 extern fn GpuTransformCullSystem_lastTraffic(s: *const State, rows_up: ?*u64, rows_down: ?*u64) void;
 extern fn GpuTransformCullSystem_destroy(s: ?*State) void;
 
@@ -153,9 +153,10 @@ pub fn fetchWorld(entity: ecs.Entity) ?Mat4 {
     return m;
 }
 
-/// Wall time of the last frame by stage, ms: inputs, rows up, device frame, rows down and placed.
-pub fn lastTimes() [4]f64 {
-    var ms = [4]f64{ 0, 0, 0, 0 };
+/// Wall time of the last frame by stage, ms: inputs, rows up, device frame, rows down and placed; query walk and
+/// slot-order rebuild (parts of the first, zero without a structural change).
+pub fn lastTimes() [6]f64 {
+    var ms = [6]f64{ 0, 0, 0, 0, 0, 0 };
     if (state) |s| GpuTransformCullSystem_lastTimes(s, &ms);
     return ms;
 }
