@@ -171,7 +171,7 @@ int yh_frame(yh_scene* s, const float* planes, uint32_t n_frusta, uint32_t flags
  * scratch (boundary counters, tile counts, visibility words, their byte counts) lies in a file-scope device array of
  * YH_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends, so the call makes no
  * hipMalloc / hipFree / event creation (kernel-timing events are not recorded on this path, nothing is deferred to a
- * later call).  Limit: n_frusta x (9 bytes per 64 entities + 4 per expand tile) + 144 <= YH_STATIC_SCRATCH_BYTES,
+ * later call).  Limit: n_frusta x (9 bytes per 64 entities + 4 per expand tile and per 262144 entities) + 144 <= YH_STATIC_SCRATCH_BYTES,
  * about 119M entity-frusta (16M entities x 7 frusta); beyond it YH_ERR_CAPACITY and nothing is launched.  All calls on
  * one GPU share that GPU's array (it keeps the last call's contents; the call clears what must start at zero): calls
  * on ONE context are ordered by its stream, calls on two contexts of the same GPU that overlap RACE.  The words of
