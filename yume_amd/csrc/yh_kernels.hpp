@@ -161,6 +161,7 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
 __device__ __forceinline__ void publish_visible(const FrameArgs& a, uint32_t chunk, bool merge_with_previous_launch,
                                                 uint32_t vmask, uint32_t bmask) {
     const uint32_t lane = threadIdx.x & 63u;
+#if !defined(YH_PUBLISH_ONE_STORE)
     for (uint32_t f = 0; f < a.n_frusta; ++f) {
         const uint64_t m = __ballot((vmask >> f) & 1u);
         const uint64_t bm = __ballot((bmask >> f) & 1u);
@@ -172,6 +173,23 @@ __device__ __forceinline__ void publish_visible(const FrameArgs& a, uint32_t chu
             if (bm) atomicAdd(&a.bcount[f], (uint32_t)__popcll(bm));
         }
     }
+#else
+    // experiment build (tools/ab_publish.sh): lane f keeps frustum f's word, ONE store of the words and one of the count
+    // bytes per wave whatever the number of frusta.  No gain at 5 frusta (cfg3 0.3594 vs 0.3581 ms): not the default.
+    uint64_t mine = 0;
+    for (uint32_t f = 0; f < a.n_frusta; ++f) {
+        const uint64_t m = __ballot((vmask >> f) & 1u);
+        const uint64_t bm = __ballot((bmask >> f) & 1u);
+        if (lane == f) mine = m;
+        if (bm && lane == 0) atomicAdd(&a.bcount[f], (uint32_t)__popcll(bm));
+    }
+    if (lane < a.n_frusta) {
+        uint64_t* w = &a.vismask[(uint64_t)lane * a.n_chunks + chunk];
+        const uint64_t word = merge_with_previous_launch ? (*w | mine) : mine;
+        *w = word;
+        a.viscnt[(uint64_t)lane * a.cnt_stride + chunk] = (uint8_t)__popcll(word);
+    }
+#endif
 }
 
 template <int BOUNDS>
