@@ -128,6 +128,16 @@ void yh_scene_destroy(yh_scene* scene);
  * parent_index[e] is the slot of e's parent (an entity of the previous level) or YH_NO_PARENT for level 0,
  * whose parent is the scene root (GameApp.zig:77,95).  level_offsets has n_levels+1 entries.           */
 int yh_upload_hierarchy(yh_scene* s, const uint32_t* parent_index, const uint32_t* level_offsets);
+/* A hierarchy that changes a little (entities created, deleted or re-parented between frames: editor/Editor.zig:590-636,
+ * GameApp.zig:204-215) without a new yh_upload_hierarchy: the host gives every level spare slots, marks the slots
+ * that hold no entity, and moves the rows of a table that changed to free slots of its level.
+ * yh_upload_parent_range: parent indices of slots [first, first + count), all of ONE level, every parent inside the
+ * level before it (level 0: values unused); level layout and launch plan stay as uploaded.
+ * yh_scene_set_alive_range (Mat4 scenes): a slot that is not alive is never listed as visible, never counted as a
+ * boundary case, never reported as changed; its rows are computed like any other, so it needs a valid parent index.
+ * All slots are alive until the first call.                                                                   */
+int yh_upload_parent_range(yh_scene* s, const uint32_t* parent_index, uint64_t first, uint64_t count);
+int yh_scene_set_alive_range(yh_scene* s, uint64_t first, uint64_t count, int alive);
 /* WorldTransform of the scene root (GameApp.zig:95); identity until set. */
 int yh_set_root(yh_scene* s, const float root_world[16]);
 /* The same from the root's 68-byte WorldTransform row as the `Up` term hands it to level-0 tables

@@ -428,3 +428,92 @@ def test_chain_replay_equals_one_level_per_launch_on_tiny_mixed_levels(ctx, orac
             assert_same_values(a[0]["m"], a[3]["m"], f"frame {frame}: world vs oracle")
             assert_same_values(a[1]["m"], a[4]["m"], f"frame {frame}: local vs oracle")
         assert np.array_equal(a[2], b[2]) and not a[0]["dirty"].any() and not a[1]["dirty"].any()
+
+
+def test_spare_slots_dead_slots_and_a_moved_row(ctx, oracle):
+    """A hierarchy that changes a little without a new yh_upload_hierarchy (yh_scene_set_alive_range,
+    yh_upload_parent_range): every level has spare slots at its end, marked dead; a dead slot is never listed and never
+    reported as changed whatever its rows hold; an entity that moves under another parent takes a spare slot of its
+    level.  Lists, change lists and matrices against the oracle's compact scene, slot by slot."""
+    from yume_amd import Scene, _lib
+
+    n, levels, spare = 40_000, 6, 37
+    lo, par, bounds, local, world = build(oracle, n, levels)
+    planes = np.concatenate([oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()[2:3]])
+    root = oracle.identity68()
+    # slot of every entity: level k's entities, then `spare` dead slots
+    slot_lo = np.array([int(lo[k]) + k * spare for k in range(levels + 1)], np.uint32)
+    level_of = np.searchsorted(lo, np.arange(n), side="right") - 1
+    slot_of = (np.arange(n) + level_of * spare).astype(np.uint32)
+    N = int(slot_lo[-1])
+    spar = np.zeros(N, np.uint32)
+    spar[slot_of] = np.where(par == 0xFFFFFFFF, 0xFFFFFFFF, slot_of[np.minimum(par, n - 1)])
+    alive = np.zeros(N, bool)
+    alive[slot_of] = True
+    for k in range(levels):  # dead slots still need a parent inside the level before theirs
+        dead = np.arange(int(lo[k + 1]) + k * spare, int(slot_lo[k + 1]))
+        spar[dead] = 0xFFFFFFFF if k == 0 else slot_lo[k - 1]
+    rng = np.random.default_rng(11)
+
+    def padded(col):  # a compact column in slot order; dead rows hold junk, dirty flags included
+        out = np.zeros(N, oracle.T68)
+        out["m"] = rng.standard_normal((N, 16)).astype(np.float32)
+        out["dirty"] = 1
+        out[slot_of] = col
+        return out
+
+    with Scene(ctx, N, n_levels=levels, n_frusta=2, local_kind=_lib.YH_LOCAL_MAT4) as s:
+        s.upload_hierarchy(spar, slot_lo)
+        b = np.zeros((N, 6), np.float32)
+        b[slot_of] = bounds
+        b[~alive] = [-1e3, -1e3, -1e3, 1e3, 1e3, 1e3]  # huge boxes: visible if anything is
+        s.upload_aabb(np.ascontiguousarray(b[:, 0:3].T), np.ascontiguousarray(b[:, 3:6].T))
+        s.upload_local_aos68(padded(local))
+        s.upload_world_aos68(padded(world))
+        s.track_changes(True)
+        for k in range(levels):
+            s.set_alive_range(int(lo[k + 1]) + k * spare, spare, False)
+        with pytest.raises(_lib.YumeHipError) as e:
+            s.set_alive_range(N - 1, 2, False)
+        assert e.value.code == _lib.YH_ERR_BAD_ARG
+
+        def check(tag):
+            oracle.frame_aos68(world, local, par, lo, root)
+            s.frame(planes, flags=0)
+            vis, bnd = oracle.cull(world, bounds, planes, n_threads=4)
+            counts, bcounts = s.counts()
+            for f in range(2):
+                assert np.array_equal(s.draw_list(f), np.sort(slot_of[np.flatnonzero(vis[f])])), f"{tag}: frustum {f}"
+                assert bcounts[f] == np.count_nonzero(bnd[f]), tag
+            sw, rw = s.changed_rows(0)
+            sl, rl = s.changed_rows(1)
+            assert alive[sw].all() and alive[sl].all(), f"{tag}: a dead slot was reported as changed"
+            dev = s.world_aos68()
+            assert_same_values(dev["m"][slot_of], world["m"], f"{tag}: world")
+            return sw
+
+        assert check("frame 0").size == n  # everything dirty: every live row, no dead one
+        assert check("frame 1").size == 0
+        # move the last entity (a leaf of the last level) under another parent: a spare slot of its level, the old one dead
+        e_, new_par = n - 1, int(lo[levels - 2]) + 5
+        old_slot, new_slot = int(slot_of[e_]), int(lo[levels]) + (levels - 1) * spare + 3
+        with pytest.raises(_lib.YumeHipError) as e:  # a parent from the wrong level
+            s.upload_parent_range(np.array([slot_of[0]], np.uint32), new_slot)
+        assert e.value.code == _lib.YH_ERR_BAD_ARG
+        with pytest.raises(_lib.YumeHipError) as e:  # a range across two levels
+            s.upload_parent_range(np.array([slot_of[new_par]] * 2, np.uint32), int(slot_lo[levels - 1]) - 1)
+        assert e.value.code == _lib.YH_ERR_BAD_ARG
+        s.set_alive_range(old_slot, 1, False)
+        s.set_alive_range(new_slot, 1, True)
+        s.upload_parent_range(np.array([slot_of[new_par]], np.uint32), new_slot)
+        par[e_] = new_par
+        slot_of[e_] = new_slot
+        alive[old_slot], alive[new_slot] = False, True
+        local["dirty"][e_] = 1  # (the reference's re-parenting leaves flags alone; here the move is made visible)
+        s.upload_local_aos68(local[e_:e_ + 1], first=new_slot)
+        s.upload_world_aos68(world[e_:e_ + 1], first=new_slot)
+        mn, mx = bounds[e_:e_ + 1, 0:3].T, bounds[e_:e_ + 1, 3:6].T
+        s.upload_aabb(np.ascontiguousarray(mn), np.ascontiguousarray(mx), first=new_slot)
+        moved = check("frame 2 (one entity moved)")
+        assert np.array_equal(moved, [new_slot])
+        assert check("frame 3").size == 0

@@ -313,6 +313,15 @@ class Scene:
         self._ck(L.lib().yh_download_changed_aos68(self._h, _ptr(slots), _ptr(w), _ptr(l), n.value, C.byref(wr)))
         return slots, w, l
 
+    def upload_parent_range(self, parents, first):
+        """Parent indices of slots [first, first + len(parents)), all of one level."""
+        parents = np.ascontiguousarray(parents, np.uint32)
+        self._ck(L.lib().yh_upload_parent_range(self._h, _ptr(parents), first, parents.size))
+
+    def set_alive_range(self, first, count, alive):
+        """Slots that hold no entity are never visible and never reported as changed (Mat4 scenes)."""
+        self._ck(L.lib().yh_scene_set_alive_range(self._h, first, count, int(bool(alive))))
+
     def changed_counts(self):
         """(rows whose WorldTransform changed, rows whose LocalTransform changed) in the last tracked frame."""
         nw, nl = C.c_uint64(), C.c_uint64()

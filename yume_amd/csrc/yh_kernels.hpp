@@ -37,6 +37,7 @@ struct FrameArgs {
     float* world;
     uint8_t* ldirty;
     uint8_t* wdirty;
+    const uint64_t* alive;  // [n_chunks] or NULL: slots that hold an entity (Mat4 scenes with spare slots); dead ones are never visible
     uint32_t* bcount;    // [YH_K_MAX_FRUSTA] boundary-case counters of this frame
     uint64_t* vismask;   // [frustum][n_chunks] one visibility bit per entity (wave ballots)
     uint8_t* viscnt;     // [frustum][cnt_stride] popcount of each visibility word (read by k_expand of small scenes)
@@ -161,10 +162,11 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
 __device__ __forceinline__ void publish_visible(const FrameArgs& a, uint32_t chunk, bool merge_with_previous_launch,
                                                 uint32_t vmask, uint32_t bmask) {
     const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t live = a.alive ? a.alive[chunk] : ~0ull;
 #if !defined(YH_PUBLISH_ONE_STORE)
     for (uint32_t f = 0; f < a.n_frusta; ++f) {
-        const uint64_t m = __ballot((vmask >> f) & 1u);
-        const uint64_t bm = __ballot((bmask >> f) & 1u);
+        const uint64_t m = __ballot((vmask >> f) & 1u) & live;
+        const uint64_t bm = __ballot((bmask >> f) & 1u) & live;
         if (lane == 0) {
             uint64_t* w = &a.vismask[(uint64_t)f * a.n_chunks + chunk];
             const uint64_t word = merge_with_previous_launch ? (*w | m) : m;
@@ -178,8 +180,8 @@ __device__ __forceinline__ void publish_visible(const FrameArgs& a, uint32_t chu
     // bytes per wave whatever the number of frusta.  No gain at 5 frusta (cfg3 0.3594 vs 0.3581 ms): not the default.
     uint64_t mine = 0;
     for (uint32_t f = 0; f < a.n_frusta; ++f) {
-        const uint64_t m = __ballot((vmask >> f) & 1u);
-        const uint64_t bm = __ballot((bmask >> f) & 1u);
+        const uint64_t m = __ballot((vmask >> f) & 1u) & live;
+        const uint64_t bm = __ballot((bmask >> f) & 1u) & live;
         if (lane == f) mine = m;
         if (bm && lane == 0) atomicAdd(&a.bcount[f], (uint32_t)__popcll(bm));
     }
@@ -921,7 +923,8 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {  // bit i = byte
 }
 __global__ __launch_bounds__(YH_BLOCK) void k_sweep_dirty(uint8_t* __restrict__ ld, uint8_t* __restrict__ wd, uint32_t n,
                                                           uint64_t* __restrict__ words, uint8_t* __restrict__ counts,
-                                                          uint32_t n_chunks, uint32_t cnt_stride) {
+                                                          uint32_t n_chunks, uint32_t cnt_stride,
+                                                          const uint64_t* __restrict__ alive) {
     const uint64_t e0 = ((uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x) * 16u;  // this lane's first entity
     const uint64_t padded = ((uint64_t)n + 63u) & ~63ull;                         // the planes' length: whole chunks
     uint32_t m = 0, ml = 0;
@@ -945,7 +948,8 @@ __global__ __launch_bounds__(YH_BLOCK) void k_sweep_dirty(uint8_t* __restrict__ 
     uint32_t lo = m | ((uint32_t)__shfl_down((int)m, 1) << 16), lol = ml | ((uint32_t)__shfl_down((int)ml, 1) << 16);
     const uint32_t hi = (uint32_t)__shfl_down((int)lo, 2), hil = (uint32_t)__shfl_down((int)lol, 2);
     if ((threadIdx.x & 3u) == 0 && e0 < padded) {
-        const uint64_t c = e0 >> 6, word = ((uint64_t)hi << 32) | lo, wordl = ((uint64_t)hil << 32) | lol;
+        const uint64_t c = e0 >> 6, live = alive ? alive[c] : ~0ull;  // a dead slot's rows are nobody's: never reported
+        const uint64_t word = (((uint64_t)hi << 32) | lo) & live, wordl = (((uint64_t)hil << 32) | lol) & live;
         words[c] = word;
         counts[c] = (uint8_t)__popcll(word);
         words[(uint64_t)n_chunks + c] = wordl;

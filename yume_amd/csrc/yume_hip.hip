@@ -94,6 +94,8 @@ struct yh_scene {
     uint32_t* chg = nullptr;          // device: 32 count words | tile counts | mask words (one allocation)
     uint32_t* chg_tilecnt = nullptr;
     uint64_t* chg_words = nullptr;
+    uint64_t* alive = nullptr;        // device [n_chunks]: bit = the slot holds an entity (yh_scene_set_alive_range); NULL: all do
+    std::vector<uint64_t> h_alive;    // its host copy
     uint32_t* chg_list = nullptr;     // device: changed slots of the last frame (WorldTransform rows: mask 0)
     uint32_t* chg_list_l = nullptr;   // device: slots whose LocalTransform row changed (mask 1)
     hipEvent_t piece_ev[YH_DL_PIECES] = {};  // yh_download_changed_rows_aos68: one per piece in flight
@@ -319,7 +321,7 @@ static void scene_free(yh_scene* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->ctx->stream_c) (void)hipStreamSynchronize(s->ctx->stream_c);
     void* ptrs[] = {s->trs, s->lmat, s->world, s->parent, s->bounds, s->mesh_id, s->ldirty, s->wdirty, s->counts,
-                    s->staging, s->d_all_counts, s->chg, s->chg_list, s->chg_list_l};
+                    s->staging, s->d_all_counts, s->chg, s->chg_list, s->chg_list_l, s->alive};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->vcount) (void)hipFree(s->vcount);
@@ -600,6 +602,58 @@ extern "C" int yh_upload_hierarchy(yh_scene* s, const uint32_t* parent_index, co
     s->level_offsets.assign(level_offsets, level_offsets + L + 1);
     s->have_hierarchy = true;
     return plan_groups(s);
+}
+
+// Parent indices of slots [first, first + count), all of ONE level; the level layout and the launch plan stay.
+extern "C" int yh_upload_parent_range(yh_scene* s, const uint32_t* parent_index, uint64_t first, uint64_t count) {
+    if (int rc = check_range(s, "yh_upload_parent_range", first, count)) return rc;
+    yh_ctx* ctx = s->ctx;
+    ARG_TRY(ctx, parent_index, "yh_upload_parent_range: parent_index is NULL");
+    if (!s->have_hierarchy) return fail(ctx, YH_ERR_STATE, "yh_upload_parent_range: call yh_upload_hierarchy first");
+    if (count == 0) return YH_OK;
+    const uint32_t L = s->desc.n_levels;
+    uint32_t k = 0;
+    while (k + 1 < L && s->level_offsets[k + 1] <= first) ++k;
+    if (first + count > s->level_offsets[k + 1])
+        return fail(ctx, YH_ERR_BAD_ARG, "yh_upload_parent_range: slots [%llu, %llu) leave level %u", (unsigned long long)first,
+                    (unsigned long long)(first + count), k);
+    for (uint64_t i = 0; i < count; ++i) {
+        const uint32_t p = parent_index[i];
+        const bool ok = k == 0 ? true : (p >= s->level_offsets[k - 1] && p < s->level_offsets[k]);  // level 0: value unused
+        if (!ok)
+            return fail(ctx, YH_ERR_BAD_ARG, "yh_upload_parent_range: slot %llu (level %u) has parent %u outside level %u",
+                        (unsigned long long)(first + i), k, p, k - 1);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_scene(s)) return rc;  // frames in flight still read the old indices
+    HIP_TRY(ctx, hipMemcpy(s->parent + first, parent_index, count * 4, hipMemcpyHostToDevice));
+    return YH_OK;
+}
+
+// Slots that hold no entity: never listed as visible, never counted as boundary cases, never reported as changed.
+extern "C" int yh_scene_set_alive_range(yh_scene* s, uint64_t first, uint64_t count, int alive) {
+    if (int rc = check_range(s, "yh_scene_set_alive_range", first, count)) return rc;
+    yh_ctx* ctx = s->ctx;
+    if (s->desc.local_kind != YH_LOCAL_MAT4)
+        return fail(ctx, YH_ERR_STATE, "yh_scene_set_alive_range: TRS scenes have no spare slots (every slot is an instance)");
+    if (count == 0) return YH_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_scene(s)) return rc;
+    if (!s->alive) {
+        s->h_alive.assign(s->n_chunks, ~0ull);
+        if (s->n & 63u) s->h_alive.back() = (1ull << (s->n & 63u)) - 1ull;
+        HIP_TRY(ctx, hipMalloc((void**)&s->alive, (uint64_t)s->n_chunks * 8));
+        HIP_TRY(ctx, hipMemcpy(s->alive, s->h_alive.data(), (uint64_t)s->n_chunks * 8, hipMemcpyHostToDevice));
+    }
+    const uint64_t c0 = first >> 6, c1 = (first + count - 1) >> 6;
+    for (uint64_t c = c0; c <= c1; ++c) {
+        const uint64_t lo = c == c0 ? (first & 63u) : 0u, hi = c == c1 ? ((first + count - 1) & 63u) : 63u;
+        const uint64_t bits = (hi == 63u ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull);
+        if (alive) s->h_alive[c] |= bits;
+        else s->h_alive[c] &= ~bits;
+    }
+    HIP_TRY(ctx, hipMemcpy(s->alive + c0, s->h_alive.data() + c0, (c1 - c0 + 1) * 8, hipMemcpyHostToDevice));
+    return YH_OK;
 }
 
 extern "C" int yh_set_root(yh_scene* s, const float root_world[16]) {
@@ -1238,6 +1292,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
     a.world = s->world;
     a.ldirty = s->ldirty;
     a.wdirty = s->wdirty;
+    a.alive = s->alive;
     a.bcount = s->counts + YH_MAX_FRUSTA * (1 + s->bset);
     // visibility words and their byte counts: frames alternate between two sets (the previous frame's may still be
     // waiting for its deferred expansion, or be on their way through the collective stream)
@@ -1406,7 +1461,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
         // PostWorldTransform / PostLocalTransform (PostTransformSystem.zig:12-37)
         if (s->track) {
             hipLaunchKernelGGL(k_sweep_dirty, dim3(cdiv(s->stride, YH_BLOCK * 16ull)), dim3(YH_BLOCK), 0, st, s->ldirty, s->wdirty,
-                               (uint32_t)s->n, s->chg_words, s->chg_cnt, s->n_chunks, s->cnt_stride);
+                               (uint32_t)s->n, s->chg_words, s->chg_cnt, s->n_chunks, s->cnt_stride, s->alive);
             HIP_TRY(ctx, hipGetLastError());
             ExpandArgs c;
             memset(&c, 0, sizeof c);
