@@ -27,10 +27,13 @@
  *              kind 2: delete the entity (children go with it, flecs' ChildOf cleanup);
  *              kind 3: re-parent under entity index bits(m[0]) (ecs.zig:470-477 setParent);
  *              kinds 4 / 5: change an entity's Mesh / a camera's view_projection (GPU build with YFH_ECS_INPUTS=1, see below)
+ *              kind 6: create entity `entity` - one whose parent[] entry is 0xFFFFFFFE, i.e. not created at start - as
+ *              a child of entity index bits(m[0]), with its local matrix (and bounds) from the scene's arrays
+ *              (GameApp.zig:204-215: new(), setParent, set LocalTransform)
  * out.bin:   per frame: world rows n x 68 B, local rows n x 68 B (all zero for deleted entities), u64 batches,
  *            u64 rows_seen, u32 up_fields_shared; GPU build + YFH2: then per frustum u32 count, u32 entity_index[count]
  *            (GPU build: batches = slot-order rebuilds so far, rows_seen = entities in the device scene), then
- *            u64 rows_up, u64 rows_down = 68-byte rows that crossed PCIe in the frame, u64 walks, u64 walks_skipped
+ *            u64 rows_up, u64 rows_down = 68-byte rows that crossed PCIe in the frame, u64 walks, u64 walks_skipped, u64 patches
  *            (query iterations done / frames that reused the last one).  GPU build, env YFH_PLAIN=1: whole columns both
  *            ways every frame instead of the incremental mode; YFH_ALWAYS_WALK=1: iterate the query every frame;
  *            YFH_NO_READBACK=1: rows stay on the device (setReadback(0)) until the last frame, which brings whole columns back;
@@ -172,8 +175,9 @@ int main(int argc, char** argv) {
     memcpy(t.matrix.v, root_m, 64);
     ecs_set_id(w, root, g_world_id, sizeof t, &t);
 
-    ecs_entity_t* ent = malloc(sizeof(ecs_entity_t) * n);
+    ecs_entity_t* ent = calloc(n, sizeof(ecs_entity_t));
     for (uint32_t e = 0; e < n; ++e) { /* level-major order = parent first (GameApp.zig:204-215) */
+        if (parent[e] == 0xFFFFFFFEu) continue; /* created later, by an edit of kind 6 */
         const ecs_entity_t p = parent[e] == 0xFFFFFFFFu ? root : ent[parent[e]];
         ent[e] = ecs_new_w_id(w, ecs_pair(EcsChildOf, p));
         memset(&t, 0, sizeof t);
@@ -223,7 +227,7 @@ int main(int argc, char** argv) {
             memcpy(m->bounds, b, sizeof b);
         }
         for (uint32_t e = 0; e < n; ++e)
-            if (e % 4) {
+            if (e % 4 && ent[e]) {
                 const FakeMesh* ref = &fake_meshes[e % 4 - 1];
                 ecs_set_id(w, ent[e], mesh_id, sizeof ref, &ref);
             }
@@ -260,7 +264,8 @@ int main(int argc, char** argv) {
             return 3;
         n_frusta = 2;
     } else if (v2) {
-        for (uint32_t e = 0; e < n; ++e) GpuTransformCullSystem_setBounds(gpu, ent[e], bounds + 6 * (size_t)e);
+        for (uint32_t e = 0; e < n; ++e)
+            if (ent[e]) GpuTransformCullSystem_setBounds(gpu, ent[e], bounds + 6 * (size_t)e);
         GpuTransformCullSystem_setFrusta(gpu, planes, n_frusta);
     }
     if (getenv("YFH_PLAIN")) GpuTransformCullSystem_setIncremental(gpu, 0);
@@ -269,8 +274,12 @@ int main(int argc, char** argv) {
     if (no_readback) GpuTransformCullSystem_setReadback(gpu, 0);
     if (getenv("YFH_THREADS")) GpuTransformCullSystem_setThreads(gpu, atoi(getenv("YFH_THREADS")));
     if (getenv("YFH_VALIDATE")) GpuTransformCullSystem_setTrustObservers(gpu, 0); /* compare every table every frame */
+    if (getenv("YFH_NO_PATCH")) GpuTransformCullSystem_setPatching(gpu, 0);       /* every structural change: walk + rebuild */
     ecs_entity_t* vis = malloc(sizeof(ecs_entity_t) * n);
     uint32_t* vis_idx = malloc(sizeof(uint32_t) * n);
+    uint32_t* idx_of_id = NULL;
+    uint32_t idx_cap = 0;
+    int idx_fresh = 0;
 #else
     (void)planes;
     const ecs_entity_t tss = make_system(w, "TransformSyncSystem", transform_sync, 3);
@@ -288,6 +297,23 @@ int main(int argc, char** argv) {
             RD(&e, 4);
             RD(&kind, 4);
             RD(m, 64);
+            if (kind == 6) {
+                uint32_t np;
+                memcpy(&np, m, 4);
+                ent[e] = ecs_new_w_id(w, ecs_pair(EcsChildOf, np == 0xFFFFFFFFu ? root : ent[np]));
+                memset(&t, 0, sizeof t);
+                memcpy(t.matrix.v, local + 16 * (size_t)e, 64);
+                ecs_set_id(w, ent[e], g_local_id, sizeof t, &t);
+#ifdef USE_GPU_SYSTEM
+                if (ecs_inputs && e % 4) {
+                    const FakeMesh* ref = &fake_meshes[e % 4 - 1];
+                    ecs_set_id(w, ent[e], mesh_id, sizeof ref, &ref);
+                } else if (!ecs_inputs && v2) {
+                    GpuTransformCullSystem_setBounds(gpu, ent[e], bounds + 6 * (size_t)e);
+                }
+#endif
+                continue;
+            }
             const ecs_entity_t target = e == 0xFFFFFFFFu ? root : ent[e];
             if (kind == 2) {
                 ecs_delete(w, target);
@@ -353,7 +379,7 @@ int main(int argc, char** argv) {
         for (int comp = 0; comp < 2; ++comp) {
             for (uint32_t e = 0; e < n; ++e) {
                 memset(&rows[e], 0, sizeof rows[e]);
-                if (!ecs_is_alive(w, ent[e])) continue;
+                if (!ent[e] || !ecs_is_alive(w, ent[e])) continue;
                 const yo_transform68* p = (const yo_transform68*)ecs_get_id(w, ent[e], comp == 0 ? g_world_id : g_local_id);
                 rows[e] = *p;
                 rows[e].pad[0] = rows[e].pad[1] = rows[e].pad[2] = 0;
@@ -366,15 +392,23 @@ int main(int argc, char** argv) {
 #ifdef USE_GPU_SYSTEM
         for (uint32_t fr = 0; fr < n_frusta; ++fr) {
             const uint64_t cnt = GpuTransformCullSystem_visible(gpu, fr, vis, n);
-            for (uint64_t i = 0; i < cnt; ++i) { /* entity ids grow with the creation index: binary search */
-                uint32_t lo_i = 0, hi_i = n - 1;
-                while (lo_i < hi_i) {
-                    const uint32_t mid = (lo_i + hi_i) / 2;
-                    if (ent[mid] < vis[i]) lo_i = mid + 1;
-                    else hi_i = mid;
+            {   /* entity id -> scene index: the low 32 bits of an id are its index in flecs' entity table */
+                uint32_t max_id = 0;
+                for (uint32_t e = 0; e < n; ++e)
+                    if ((uint32_t)ent[e] > max_id) max_id = (uint32_t)ent[e];
+                if (max_id >= idx_cap) {
+                    free(idx_of_id);
+                    idx_cap = max_id + 1024;
+                    idx_of_id = malloc(sizeof(uint32_t) * idx_cap);
+                    idx_fresh = 0;
                 }
-                vis_idx[i] = lo_i;
+                if (!idx_fresh || n_edits) {
+                    for (uint32_t e = 0; e < n; ++e)
+                        if (ent[e]) idx_of_id[(uint32_t)ent[e]] = e;
+                    idx_fresh = 1;
+                }
             }
+            for (uint64_t i = 0; i < cnt; ++i) vis_idx[i] = idx_of_id[(uint32_t)vis[i]];
             const uint32_t c32 = (uint32_t)cnt;
             fwrite(&c32, 4, 1, fout);
             fwrite(vis_idx, 4, c32, fout);
@@ -385,6 +419,8 @@ int main(int argc, char** argv) {
         uint64_t walk_stats[2];
         GpuTransformCullSystem_walkStats(gpu, &walk_stats[0], &walk_stats[1]);
         fwrite(walk_stats, 8, 2, fout);
+        const uint64_t patches = GpuTransformCullSystem_patches(gpu);
+        fwrite(&patches, 8, 1, fout);
 #endif
     }
 #ifdef USE_GPU_SYSTEM

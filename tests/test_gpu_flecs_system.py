@@ -58,8 +58,8 @@ def read_out(path, n, n_frames, n_frusta, T68, gpu=False):
             vis.append(np.frombuffer(raw, np.uint32, c, pos + 4).copy())
             pos += 4 + 4 * c
         if gpu:
-            vis.append(struct.unpack_from("<QQQQ", raw, pos))  # last element: (rows up, rows down, walks, skipped)
-            pos += 32
+            vis.append(struct.unpack_from("<QQQQQ", raw, pos))  # last element: (rows up, rows down, walks, skipped, patches)
+            pos += 40
         res.append((w, l, a, b, vis))
     assert pos == len(raw)
     return res
@@ -71,10 +71,13 @@ def reparent_arg(index):
     return m
 
 
-@pytest.mark.parametrize("plain,always_walk,validate", [(False, False, False), (True, False, False), (False, True, False), (False, False, True)],
-                         ids=["incremental", "whole-columns", "incremental-always-walk", "incremental-validate-every-frame"])
+@pytest.mark.parametrize("plain,always_walk,validate,no_patch",
+                         [(False, False, False, False), (True, False, False, False), (False, True, False, False), (False, False, True, False),
+                          (False, False, False, True)],
+                         ids=["incremental", "whole-columns", "incremental-always-walk", "incremental-validate-every-frame",
+                              "incremental-no-patching"])
 @pytest.mark.parametrize("n,levels", [(10_000, 1), (4096, 8), (50_000, 6)])
-def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, levels, plain, always_walk, validate):
+def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, levels, plain, always_walk, validate, no_patch):
     rng = np.random.default_rng(n + levels)
     lo = oracle.synth_level_offsets(n, levels)
     par = oracle.synth_parents(lo)
@@ -116,28 +119,36 @@ def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, le
     env.pop("YFH_VALIDATE", None)
     if validate:
         env["YFH_VALIDATE"] = "1"
+    env.pop("YFH_NO_PATCH", None)
+    if no_patch:
+        env["YFH_NO_PATCH"] = "1"
     subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
     cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
     gpu = read_out(out_g, n, len(frames), planes.shape[0], oracle.T68, gpu=True)
 
     alive = np.ones(n, bool)
-    rebuilds_before = 0
+    rebuilds_before = patches_before = 0
+    # leaf deletions and re-parentings at the same depth are patched (no walk, no rebuild) in the default mode
+    patching = not (plain or always_walk or validate or no_patch)
     for fi, ((cw, cl, _, rows, _), (gw, gl, rebuilds, g_rows, vis)) in enumerate(zip(cpu, gpu)):
         for e, kind, _m in frames[fi]:
             if kind == 2:
                 alive[e] = False
         with np.errstate(all="ignore"):
             # IEEE value equality; the only representation freedom is the sign of a zero (compose/mul)
-            traffic = f"(rows up, rows down, walks, walks skipped) = {vis[-1]}"
+            traffic = f"(rows up, rows down, walks, walks skipped, patches) = {vis[-1]}"
             bad = np.flatnonzero(~np.all((gw["m"] == cw["m"]) | (np.isnan(gw["m"]) & np.isnan(cw["m"])), axis=1))
             assert bad.size == 0, f"frame {fi}: {bad.size} world matrices differ, first rows {bad[:8]} {traffic}"
             assert np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi}: local matrices {traffic}"
         assert np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"]), f"frame {fi}: dirty bytes"
         assert g_rows == rows == alive.sum()
         structural = any(kind in (2, 3) for _e, kind, _m in frames[fi])
-        assert rebuilds == rebuilds_before + (1 if (fi == 0 or structural) else 0), f"frame {fi}: rebuild count"
-        rebuilds_before = rebuilds
-        up, down, walks, skipped = vis[-1]
+        up, down, walks, skipped, patches = vis[-1]
+        # (one level = ONE table of n rows: moving it whole is no patch, the system rebuilds)
+        patched = structural and patching and levels > 1
+        assert rebuilds == rebuilds_before + (1 if (fi == 0 or (structural and not patched)) else 0), f"frame {fi}: rebuild count {traffic}"
+        assert patches == patches_before + (1 if patched else 0), f"frame {fi}: patch count {traffic}"
+        rebuilds_before, patches_before = rebuilds, patches
         assert walks + skipped == fi + 1
         if always_walk:
             assert skipped == 0
@@ -199,12 +210,13 @@ def test_results_can_stay_on_the_device_until_readback_is_switched_on(oracle, tm
         idx = np.flatnonzero(alive)
         exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[idx]), np.ascontiguousarray(bounds[idx]), planes)
         assert np.array_equal(np.sort(vis[0]), idx[np.flatnonzero(exp_vis[0])]), f"frame {fi}: visible set (device state)"
-        up, down, _walks, _skipped = vis[-1]
+        up, down, _walks, _skipped, _patches = vis[-1]
         structural = any(kind in (2, 3) for _e, kind, _m in frames[fi])
         if fi + 1 < len(frames):
             assert down == 0 or structural or fi == 0, f"frame {fi}: rows came back although readback is off"
         else:  # the last frame ran with readback on: whole columns came home
-            assert down == 2 * g_rows
+            # (both columns whole: the rows and the spare slots every level ends in)
+            assert 2 * g_rows <= down <= 2 * (g_rows + g_rows // 8 + 64 * levels)
             with np.errstate(all="ignore"):
                 assert np.array_equal(gw["m"], cw["m"], equal_nan=True) and np.array_equal(gl["m"], cl["m"], equal_nan=True)
             assert np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"])

@@ -137,6 +137,24 @@ struct GpuTransformCullSystem {
     uint64_t last_up_rows, last_down_rows;
     double last_ms[6];       /* the last frame's wall time: tables + inputs, rows up, device frame, rows down and placed; of the first: query walk, slot-order rebuild */
 
+    /* Small structural changes without a rebuild (patch(), below).  Every level's range of slots ends in spare slots,
+     * dead on the device (yh_scene_set_alive_range); the observers list the tables rows entered or left; the rows of
+     * such a table move to spare slots of its level, its old slots die. */
+    int patching;                 /* default on; needs incremental mode, readback, trusted observers */
+    uint64_t n_slots;             /* slots of the device scene: rows + spare */
+    uint32_t level_begin[YH_MAX_LEVELS + 1];
+    uint32_t level_fill[YH_MAX_LEVELS]; /* first free slot of every level's range */
+    ecs_table_t** touched;        /* tables with one of the components that rows entered or left since the last frame */
+    uint32_t n_touched, cap_touched;
+    int need_full;                /* an event patch() cannot follow: a table deleted, too many tables touched */
+    int walk_cache_valid;         /* cached_* describe the batches (false after a patch: the next walk rebuilds) */
+    uint32_t* cached_slot;        /* per batch: slot_begin as the last rebuild assigned it */
+    Map batch_by_table;           /* table -> index into batches[] */
+    Map child_batches;            /* entity -> first batch whose rows have it as their parent */
+    uint32_t* next_child;         /* per batch: next batch with the same parent (UINT32_MAX: none) */
+    uint64_t slot_entries;        /* entries put into slot_of (stale ones stay until the next rebuild) */
+    uint64_t patches, last_patch_tables;
+
     int status;
     uint64_t rebuilds;
 };
@@ -176,6 +194,12 @@ static int map_get(const Map* m, ecs_entity_t k, uint32_t* v) {
         i = (i + 1) & (m->cap - 1);
     }
     return 0;
+}
+
+/* entity -> slot.  Entries of entities that left since the last rebuild stay in the map (patch() does not erase): an
+ * entry counts only while the slot still names the entity. */
+static int slot_lookup(const GpuTransformCullSystem* s, ecs_entity_t e, uint32_t* slot) {
+    return s->slot_of.e && map_get(&s->slot_of, e, slot) && *slot < s->n_slots && s->entity_of_slot[*slot] == e;
 }
 
 static BoundsEntry* bounds_find(const GpuTransformCullSystem* s, ecs_entity_t k) {
@@ -262,7 +286,7 @@ static int walk(GpuTransformCullSystem* s, ecs_iter_t* it) {
 }
 
 static int same_as_last_walk(const GpuTransformCullSystem* s) {
-    if (!s->scene || s->n != s->cached_n || s->n_batches != s->cached_batches) return 0;
+    if (!s->scene || !s->walk_cache_valid || s->n != s->cached_n || s->n_batches != s->cached_batches) return 0;
     for (uint32_t i = 0; i < s->n_batches; ++i)
         if (s->batches[i].src != s->cached_src[i] || s->batches[i].count != s->cached_counts[i]) return 0;
     return memcmp(s->walk_entities, s->cached_entities, s->n * sizeof(ecs_entity_t)) == 0;
@@ -280,6 +304,18 @@ static void free_stage(GpuTransformCullSystem* s) {
     }
     s->stage_w = s->stage_l = NULL;
     s->pinned = 0;
+}
+
+/* table -> batch, parent -> batches of its children (lists through next_child) */
+static void link_batch(GpuTransformCullSystem* s, uint32_t b) {
+    const Batch* bt = &s->batches[b];
+    if (bt->table) map_put(&s->batch_by_table, (ecs_entity_t)(uintptr_t)bt->table, b);
+    uint32_t head = UINT32_MAX;
+    if (bt->src) {
+        (void)map_get(&s->child_batches, bt->src, &head);
+        map_put(&s->child_batches, bt->src, b);
+    }
+    s->next_child[b] = head;
 }
 
 /* ---- rebuild of the slot order ----------------------------------------------------------------------------- */
@@ -302,7 +338,8 @@ static int rebuild(GpuTransformCullSystem* s) {
     uint32_t* parent_batch = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
     uint32_t* parent_row = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1)); /* walk row of the parent */
     uint32_t* key = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
-    uint32_t* parent_index = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
+    /* (slots = rows + the spare slots of every level: at most an eighth more, and 64 per level) */
+    uint32_t* parent_index = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n + n / 8 + 64u * (YH_MAX_LEVELS + 1)));
     uint32_t* stack = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
     KeyedBatch* keyed = (KeyedBatch*)malloc(sizeof(KeyedBatch) * (nb ? nb : 1));
     uint32_t level_offsets[YH_MAX_LEVELS + 1];
@@ -348,7 +385,9 @@ static int rebuild(GpuTransformCullSystem* s) {
         rc = YH_ERR_UNSUPPORTED;
         goto done;
     }
-    /* level by level: order the level's batches by the slot of their parent, hand out slots */
+    /* level by level: order the level's batches by the slot of their parent, hand out slots; with patching on every
+     * level's range ends in spare slots for the tables that change later (patch()) */
+    const int spare_slots = s->patching && s->incremental;
     uint32_t placed = 0, slot = 0;
     for (uint32_t lvl = 0; lvl < n_levels; ++lvl) {
         level_offsets[lvl] = slot;
@@ -374,16 +413,25 @@ static int rebuild(GpuTransformCullSystem* s) {
             for (uint32_t r = 0; r < b->count; ++r) parent_index[slot + r] = p;
             slot += b->count;
         }
+        s->level_fill[lvl] = slot;
+        if (spare_slots) {
+            const uint32_t rows = slot - level_offsets[lvl], spare = rows / 8u > 64u ? rows / 8u : 64u;
+            /* a dead slot is computed like any other: it needs a parent inside the level before its own */
+            for (uint32_t r = 0; r < spare; ++r) parent_index[slot + r] = lvl == 0 ? YH_NO_PARENT : level_offsets[lvl - 1];
+            slot += spare;
+        }
     }
     level_offsets[n_levels] = slot;
+    const uint64_t N = slot; /* slots of the device scene */
+    memcpy(s->level_begin, level_offsets, sizeof(uint32_t) * (n_levels + 1));
 
     const uint32_t want_bounds = s->mesh_id ? YH_BOUNDS_MESH_TABLE : YH_BOUNDS_PER_ENTITY;
-    if (!s->scene || s->scene_entities != n || s->scene_levels != n_levels || s->scene_bounds_kind != want_bounds) {
+    if (!s->scene || s->scene_entities != N || s->scene_levels != n_levels || s->scene_bounds_kind != want_bounds) {
         if (s->scene) yh_scene_destroy(s->scene);
         s->scene = NULL;
         yh_scene_desc d;
         memset(&d, 0, sizeof d);
-        d.n_entities = n;
+        d.n_entities = N;
         d.n_levels = n_levels;
         d.n_frusta = YH_MAX_FRUSTA;
         d.local_kind = YH_LOCAL_MAT4;
@@ -392,28 +440,39 @@ static int rebuild(GpuTransformCullSystem* s) {
         s->scene_bounds_kind = want_bounds;
         s->n_meshes = 0;
         if ((rc = yh_scene_create(s->ctx, &d, &s->scene)) != YH_OK) goto done;
-        s->scene_entities = n;
+        s->scene_entities = N;
         s->scene_levels = n_levels;
         /* the staging columns every row crosses PCIe through: page-locked, so the copies run at link speed */
         free_stage(s);
-        s->stage_w = (uint8_t*)yh_host_alloc(s->ctx, (uint64_t)n * ROW);
-        s->stage_l = (uint8_t*)yh_host_alloc(s->ctx, (uint64_t)n * ROW);
+        s->stage_w = (uint8_t*)yh_host_alloc(s->ctx, N * ROW);
+        s->stage_l = (uint8_t*)yh_host_alloc(s->ctx, N * ROW);
         s->pinned = s->stage_w && s->stage_l;
         if (!s->pinned) { /* no page-locked memory to be had: ordinary memory works, slower */
             free_stage(s);
-            s->stage_w = (uint8_t*)malloc((size_t)n * ROW);
-            s->stage_l = (uint8_t*)malloc((size_t)n * ROW);
+            s->stage_w = (uint8_t*)malloc((size_t)N * ROW);
+            s->stage_l = (uint8_t*)malloc((size_t)N * ROW);
         }
-        ecs_entity_t* eo = (ecs_entity_t*)realloc(s->entity_of_slot, (size_t)n * sizeof(ecs_entity_t));
+        ecs_entity_t* eo = (ecs_entity_t*)realloc(s->entity_of_slot, (size_t)N * sizeof(ecs_entity_t));
         if (eo) s->entity_of_slot = eo;
-        uint32_t* bo = (uint32_t*)realloc(s->batch_of, (size_t)n * sizeof(uint32_t));
+        uint32_t* bo = (uint32_t*)realloc(s->batch_of, (size_t)N * sizeof(uint32_t));
         if (bo) s->batch_of = bo;
         if (!s->stage_w || !s->stage_l || !eo || !bo) {
             rc = YH_ERR_OOM;
             goto done;
         }
+        memset(s->stage_w, 0, (size_t)N * ROW); /* the rows of spare slots travel with the whole columns: defined bytes */
+        memset(s->stage_l, 0, (size_t)N * ROW);
     }
+    s->n_slots = N;
     if ((rc = yh_upload_hierarchy(s->scene, parent_index, level_offsets)) != YH_OK) goto done;
+    if (spare_slots) { /* (a scene that is reused may carry the dead slots of earlier patches) */
+        if ((rc = yh_scene_set_alive_range(s->scene, 0, N, 1)) != YH_OK) goto done;
+        for (uint32_t lvl = 0; lvl < n_levels; ++lvl)
+            if ((rc = yh_scene_set_alive_range(s->scene, s->level_fill[lvl], level_offsets[lvl + 1] - s->level_fill[lvl], 0)) != YH_OK)
+                goto done;
+    }
+    memset(s->entity_of_slot, 0, (size_t)N * sizeof(ecs_entity_t)); /* 0: the slot holds no entity */
+    memset(s->batch_of, 0xFF, (size_t)N * sizeof(uint32_t));
     for (uint32_t b = 0; b < nb; ++b)
         memcpy(s->entity_of_slot + s->batches[b].slot_begin, s->walk_entities + s->batches[b].walk_begin,
                sizeof(ecs_entity_t) * s->batches[b].count);
@@ -423,26 +482,39 @@ static int rebuild(GpuTransformCullSystem* s) {
     /* entity -> slot, and the per-slot buffers of the incremental mode */
     free(s->slot_of.e);
     s->slot_of.e = NULL;
-    if (map_init(&s->slot_of, n) != 0) {
+    if (map_init(&s->slot_of, N) != 0) {
         rc = YH_ERR_OOM;
         goto done;
     }
-    for (uint64_t e = 0; e < n; ++e) map_put(&s->slot_of, s->entity_of_slot[e], (uint32_t)e);
+    for (uint64_t e = 0; e < N; ++e)
+        if (s->entity_of_slot[e]) map_put(&s->slot_of, s->entity_of_slot[e], (uint32_t)e);
+    s->slot_entries = n;
     for (int k = 0; k < 2; ++k) {
         free(s->stamp[k]);
-        s->stamp[k] = (uint32_t*)calloc((size_t)(n ? n : 1), sizeof(uint32_t));
+        s->stamp[k] = (uint32_t*)calloc((size_t)(N ? N : 1), sizeof(uint32_t));
     }
     /* the slots of sparse uploads / changed rows cross PCIe too: page-locked like the staging columns when possible */
     if (s->slot_buf_pinned) yh_host_free(s->ctx, s->slot_buf);
     else free(s->slot_buf);
-    s->slot_buf = (uint32_t*)yh_host_alloc(s->ctx, sizeof(uint32_t) * (uint64_t)(n ? n : 1));
+    s->slot_buf = (uint32_t*)yh_host_alloc(s->ctx, sizeof(uint32_t) * (uint64_t)(N ? N : 1));
     s->slot_buf_pinned = s->slot_buf != NULL;
-    if (!s->slot_buf) s->slot_buf = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n ? n : 1));
+    if (!s->slot_buf) s->slot_buf = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(N ? N : 1));
     s->epoch = 0;
     if (!s->stamp[0] || !s->stamp[1] || !s->slot_buf) {
         rc = YH_ERR_OOM;
         goto done;
     }
+    /* table -> batch and parent -> batches of its children, for patch() */
+    free(s->batch_by_table.e);
+    free(s->child_batches.e);
+    free(s->next_child);
+    s->batch_by_table.e = s->child_batches.e = NULL;
+    s->next_child = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(s->cap_batches ? s->cap_batches : 1));
+    if (!s->next_child || map_init(&s->batch_by_table, (uint64_t)nb + 1024) != 0 || map_init(&s->child_batches, (uint64_t)nb + 1024) != 0) {
+        rc = YH_ERR_OOM;
+        goto done;
+    }
+    for (uint32_t b = 0; b < nb; ++b) link_batch(s, b);
     if ((rc = yh_scene_track_changes(s->scene, s->incremental)) != YH_OK) goto done;
 
     /* remember this walk */
@@ -453,13 +525,15 @@ static int rebuild(GpuTransformCullSystem* s) {
         int32_t* cl = (int32_t*)realloc(s->cached_levels, (size_t)(nb ? nb : 1) * sizeof(int32_t));
         ecs_table_t** ct = (ecs_table_t**)realloc(s->cached_tables, (size_t)(nb ? nb : 1) * sizeof(ecs_table_t*));
         int32_t* ccol = (int32_t*)realloc(s->cached_cols, (size_t)(nb ? nb : 1) * 2 * sizeof(int32_t));
+        uint32_t* cslot = (uint32_t*)realloc(s->cached_slot, (size_t)(nb ? nb : 1) * sizeof(uint32_t));
+        if (cslot) s->cached_slot = cslot;
         if (ct) s->cached_tables = ct;
         if (ccol) s->cached_cols = ccol;
         if (cl) s->cached_levels = cl;
         if (ce) s->cached_entities = ce;
         if (cs) s->cached_src = cs;
         if (cc) s->cached_counts = cc;
-        if (!ce || !cs || !cc || !cl || !ct || !ccol) {
+        if (!ce || !cs || !cc || !cl || !ct || !ccol || !cslot) {
             s->cached_n = 0;
             s->cached_batches = 0;
             rc = YH_ERR_OOM;
@@ -473,9 +547,11 @@ static int rebuild(GpuTransformCullSystem* s) {
             ct[b] = s->batches[b].table;
             ccol[2 * b] = s->batches[b].col_w;
             ccol[2 * b + 1] = s->batches[b].col_l;
+            cslot[b] = s->batches[b].slot_begin;
         }
         s->cached_n = n;
         s->cached_batches = nb;
+        s->walk_cache_valid = 1;
     }
     s->rebuilds += 1;
 done:
@@ -495,7 +571,7 @@ done:
  * entities that have none, a u32 id per entity.  setBounds overrides get entries of their own.  Tables are walked
  * column-wise: one pointer compare per row, one hash lookup per run of rows that share a mesh. */
 static int upload_bounds_from_meshes(GpuTransformCullSystem* s) {
-    const uint64_t n = s->n;
+    const uint64_t n = s->n_slots;
     int rc = YH_OK;
     uint32_t* ids = (uint32_t*)calloc((size_t)(n ? n : 1), sizeof(uint32_t));
     float* table = (float*)calloc((size_t)MESH_TABLE_MAX * 6, sizeof(float));
@@ -552,7 +628,7 @@ static int upload_bounds_from_meshes(GpuTransformCullSystem* s) {
     }
     if (rc == YH_OK && s->bounds_n) /* per-entity overrides */
         for (uint64_t e = 0; e < n && rc == YH_OK; ++e) {
-            const BoundsEntry* o = bounds_find(s, s->entity_of_slot[e]);
+            const BoundsEntry* o = s->entity_of_slot[e] ? bounds_find(s, s->entity_of_slot[e]) : NULL;
             if (!o) continue;
             if (n_meshes == MESH_TABLE_MAX) {
                 rc = YH_ERR_CAPACITY;
@@ -590,12 +666,12 @@ done:
 
 static int upload_bounds(GpuTransformCullSystem* s) {
     if (s->scene_bounds_kind == YH_BOUNDS_MESH_TABLE) return upload_bounds_from_meshes(s);
-    const uint64_t n = s->n;
+    const uint64_t n = s->n_slots;
     float* planes = (float*)calloc((size_t)n * 6, sizeof(float)); /* no bounds = empty box at the origin */
     if (!planes) return YH_ERR_OOM;
     if (s->bounds_n)
         for (uint64_t e = 0; e < n; ++e) {
-            const BoundsEntry* b = bounds_find(s, s->entity_of_slot[e]);
+            const BoundsEntry* b = s->entity_of_slot[e] ? bounds_find(s, s->entity_of_slot[e]) : NULL;
             if (b)
                 for (int k = 0; k < 6; ++k) planes[(size_t)k * n + e] = b->mm[k];
         }
@@ -609,12 +685,10 @@ static int upload_bounds(GpuTransformCullSystem* s) {
 
 /* when slots are restored from the cached order only slot_begin / level need refreshing: same walk, same order */
 static void restore_slots(GpuTransformCullSystem* s) {
-    uint32_t slot = 0;
     for (uint32_t i = 0; i < s->n_batches; ++i) {
-        Batch* b = &s->batches[s->order[i]];
-        b->level = s->cached_levels[s->order[i]];
-        b->slot_begin = slot;
-        slot += b->count;
+        Batch* b = &s->batches[i];
+        b->level = s->cached_levels[i];
+        b->slot_begin = s->cached_slot[i]; /* (levels end in spare slots: not a running sum of the counts) */
     }
 }
 
@@ -649,20 +723,34 @@ static void fill_batch_of(GpuTransformCullSystem* s) {
 /* Structural events: an id came to or left a table that holds one of the two components (entities created, deleted,
  * re-parented, or moved between archetypes by an unrelated component: in each case rows enter, leave or move inside
  * tables this system has cached), or such a table was created or deleted. */
-static void note_structure(ecs_iter_t* it) {
-    GpuTransformCullSystem* s = (GpuTransformCullSystem*)it->ctx;
-    if (s->structure_dirty) return;
-    const ecs_table_t* tables[2] = {it->table, it->other_table};
-    for (int k = 0; k < 2; ++k) {
-        if (!tables[k]) continue;
-        if (ecs_table_get_column_index(it->real_world, tables[k], s->local_id) >= 0 ||
-            ecs_table_get_column_index(it->real_world, tables[k], s->world_id) >= 0) {
-            s->structure_dirty = 1;
+#define MAX_TOUCHED 65536u
+static void touch_table(GpuTransformCullSystem* s, const ecs_world_t* w, ecs_table_t* t) {
+    if (!t) return;
+    if (ecs_table_get_column_index(w, t, s->local_id) < 0 && ecs_table_get_column_index(w, t, s->world_id) < 0) return;
+    s->structure_dirty = 1;
+    if (s->need_full || (s->n_touched && s->touched[s->n_touched - 1] == t)) return; /* (runs of events on one table) */
+    if (s->n_touched == s->cap_touched) {
+        const uint32_t cap = s->cap_touched ? s->cap_touched * 2 : 256;
+        ecs_table_t** g = cap > MAX_TOUCHED ? NULL : (ecs_table_t**)realloc(s->touched, sizeof(ecs_table_t*) * cap);
+        if (!g) { /* too many tables for a patch (or no memory): the next frame walks the query */
+            s->need_full = 1;
             return;
         }
+        s->touched = g;
+        s->cap_touched = cap;
     }
+    s->touched[s->n_touched++] = t;
 }
-static void note_table(ecs_iter_t* it) { ((GpuTransformCullSystem*)it->ctx)->structure_dirty = 1; }
+static void note_structure(ecs_iter_t* it) {
+    GpuTransformCullSystem* s = (GpuTransformCullSystem*)it->ctx;
+    touch_table(s, it->real_world, it->table);
+    touch_table(s, it->real_world, it->other_table);
+}
+static void note_table(ecs_iter_t* it) {
+    GpuTransformCullSystem* s = (GpuTransformCullSystem*)it->ctx;
+    s->structure_dirty = 1;
+    if (it->event == EcsOnTableDelete) s->need_full = 1; /* a listed or cached table pointer may dangle now */
+}
 
 /* OnSet observers: the same events that run the components' onSet hooks */
 static void note_set(ecs_iter_t* it, int k) {
@@ -692,7 +780,7 @@ static void on_set_world(ecs_iter_t* it) { note_set(it, 1); }
  * ids compared: catches rows that moved between tables because an unrelated component came or went).  Column
  * pointers are fetched afresh.  Returns 1 if the batches were restored, 0 if the iterator has to be walked. */
 static int restore_walk(GpuTransformCullSystem* s, const ecs_iter_t* it) {
-    if (!s->scene || !s->cached_n || !s->walk_is_whole_tables || !it->query) return 0;
+    if (!s->scene || !s->cached_n || !s->walk_cache_valid || !s->walk_is_whole_tables || !it->query) return 0;
     if (it->query->cache_kind != EcsQueryCacheAll) return 0; /* no cache, no match count */
     if (ecs_query_match_count(it->query) != s->cached_match_count) return 0;
     uint64_t row = 0;
@@ -807,7 +895,7 @@ static int fetch_changed(GpuTransformCullSystem* s, int k, uint64_t m) {
     uint64_t helpers = m / ROWS_PER_THREAD_MIN;
     if (helpers > (uint64_t)s->threads) helpers = (uint64_t)s->threads;
     if (helpers < 2) {
-        if ((rc = yh_download_changed_rows_aos68(s->scene, which, s->slot_buf, stage, s->n, &written, NULL, NULL)) != YH_OK) return rc;
+        if ((rc = yh_download_changed_rows_aos68(s->scene, which, s->slot_buf, stage, s->n_slots, &written, NULL, NULL)) != YH_OK) return rc;
         if (written != m) return YH_ERR_STATE; /* (the counts were read a moment ago: they agree) */
         scatter_range(s, k, s->slot_buf, stage, 0, written);
         return YH_OK;
@@ -824,7 +912,7 @@ static int fetch_changed(GpuTransformCullSystem* s, int k, uint64_t m) {
     t.helpers = (uint32_t)helpers;
     pthread_t first;
     const int started = pthread_create(&first, NULL, scatter_first_helper, &t) == 0;
-    rc = yh_download_changed_rows_aos68(s->scene, which, s->slot_buf, stage, s->n, &written, scatter_rows_ready, &t);
+    rc = yh_download_changed_rows_aos68(s->scene, which, s->slot_buf, stage, s->n_slots, &written, scatter_rows_ready, &t);
     if (rc != YH_OK || written != m) atomic_store(&t.stop, 1);
     else scatter_work(&t); /* every row is in place: this thread joins in, and finishes alone if no helper started */
     if (started) pthread_join(first, NULL);
@@ -846,11 +934,11 @@ static int catch_up_by_entity(GpuTransformCullSystem* s) {
     for (int k = 0; k < 2; ++k)
         for (uint64_t i = 0; i < s->n_dirty[k]; ++i) {
             uint32_t slot;
-            if (map_get(&s->slot_of, s->dirty[k][i], &slot) && slot < n) keep[slot] |= (uint8_t)(1 << k);
+            if (slot_lookup(s, s->dirty[k][i], &slot) && slot < n) keep[slot] |= (uint8_t)(1 << k);
         }
     for (uint64_t slot = 0; slot < n; ++slot) {
         const ecs_entity_t e = s->entity_of_slot[slot];
-        if (!ecs_is_alive(s->world, e)) continue;
+        if (!e || !ecs_is_alive(s->world, e)) continue;
         if (!(keep[slot] & 2)) {
             void* w = (void*)ecs_get_id(s->world, e, s->world_id);
             if (w) memcpy(w, s->stage_w + slot * ROW, ROW);
@@ -881,7 +969,7 @@ static uint64_t gather_dirty(GpuTransformCullSystem* s, int k, uint8_t* stage) {
         const uint32_t nb = (uint32_t)(nd - i0 < GATHER_BLOCK ? nd - i0 : GATHER_BLOCK);
         for (uint32_t j = 0; j < nb; ++j) __builtin_prefetch(&s->slot_of.e[hash64(ents[i0 + j]) & mask]);
         for (uint32_t j = 0; j < nb; ++j) {
-            if (!map_get(&s->slot_of, ents[i0 + j], &slot[j])) {
+            if (!slot_lookup(s, ents[i0 + j], &slot[j])) {
                 slot[j] = UINT32_MAX; /* not a row of this system (the root, or an entity deleted since) */
                 continue;
             }
@@ -913,6 +1001,237 @@ static uint64_t gather_dirty(GpuTransformCullSystem* s, int k, uint8_t* stage) {
     return m;
 }
 
+/* ---- small structural changes without a rebuild ----------------------------------------------------------- */
+typedef struct PatchItem {
+    ecs_table_t* table;
+    uint32_t old_batch; /* UINT32_MAX: the table was not cached */
+    uint32_t count;     /* rows it holds now (0: it left the query) */
+    int32_t col_w, col_l, level;
+    ecs_entity_t src;
+    uint32_t new_batch;
+} PatchItem;
+static int by_ptr(const void* a, const void* b) {
+    const uintptr_t x = (uintptr_t) * (ecs_table_t* const*)a, y = (uintptr_t) * (ecs_table_t* const*)b;
+    return x < y ? -1 : (x > y);
+}
+static int by_level(const void* a, const void* b) {
+    const PatchItem* x = (const PatchItem*)a;
+    const PatchItem* y = (const PatchItem*)b;
+    return x->level < y->level ? -1 : (x->level > y->level);
+}
+static int32_t level_of_slot(const GpuTransformCullSystem* s, uint32_t slot) {
+    int32_t l = 0;
+    while ((uint32_t)l + 1 < s->n_levels && s->level_begin[l + 1] <= slot) ++l;
+    return l;
+}
+static int upload_parent_run(GpuTransformCullSystem* s, uint32_t first, uint32_t count, uint32_t parent_slot) {
+    for (uint32_t r = 0; r < count; ++r) s->slot_buf[r] = parent_slot; /* (slot_buf: n_slots words, free between its uses) */
+    return yh_upload_parent_range(s->scene, s->slot_buf, first, count);
+}
+
+/* The tables the observers listed are compared with their batches; the rows of one that changed (entities created in
+ * it, deleted from it, moved in or out by a re-parenting or by an unrelated component) move to spare slots of its
+ * level, its old slots die, the children of every row that moved learn their parent's new slot.  Nothing else is
+ * touched: no query walk, no re-sort, no column upload beyond the moved rows.
+ * Returns YH_OK (the batches follow the world again), 1 (not a case for a patch: walk and rebuild), or an error. */
+static int patch(GpuTransformCullSystem* s) {
+    int rc = YH_OK;
+    uint32_t nt = 0;
+    if (s->n_touched) {
+        qsort(s->touched, s->n_touched, sizeof(ecs_table_t*), by_ptr);
+        for (uint32_t i = 0; i < s->n_touched; ++i)
+            if (!nt || s->touched[nt - 1] != s->touched[i]) s->touched[nt++] = s->touched[i];
+    }
+    s->last_patch_tables = nt;
+    if (!nt) return YH_OK;
+    PatchItem* items = (PatchItem*)calloc(nt, sizeof(PatchItem));
+    Map incoming = {0}; /* entities of the tables' new contents */
+    uint64_t rows_in = 0, rows_out = 0, need[YH_MAX_LEVELS];
+    uint32_t ni = 0;
+    memset(need, 0, sizeof need);
+    if (!items) return YH_ERR_OOM;
+    /* what every listed table holds now, and where its rows belong */
+    for (uint32_t i = 0; i < nt; ++i) {
+        ecs_table_t* t = s->touched[i];
+        PatchItem it;
+        memset(&it, 0, sizeof it);
+        it.table = t;
+        it.old_batch = it.new_batch = UINT32_MAX;
+        uint32_t ob;
+        if (map_get(&s->batch_by_table, (ecs_entity_t)(uintptr_t)t, &ob) && ob < s->n_batches && s->batches[ob].table == t && s->batches[ob].count)
+            it.old_batch = ob;
+        it.col_w = ecs_table_get_column_index(s->world, t, s->world_id);
+        it.col_l = ecs_table_get_column_index(s->world, t, s->local_id);
+        it.count = it.col_w >= 0 && it.col_l >= 0 ? (uint32_t)ecs_table_count(t) : 0u;
+        if (it.old_batch == UINT32_MAX && !it.count) continue;
+        const ecs_entity_t* ents = it.count ? ecs_table_entities(t) : NULL;
+        if (it.old_batch != UINT32_MAX) {
+            const Batch* b = &s->batches[it.old_batch];
+            it.src = b->src;
+            it.level = b->level;
+            if (it.count == b->count && memcmp(ents, s->entity_of_slot + b->slot_begin, sizeof(ecs_entity_t) * it.count) == 0)
+                continue; /* same rows in the same order (a component came and went) */
+            rows_out += b->count;
+        } else {
+            it.src = ecs_get_parent(s->world, ents[0]); /* ChildOf is part of the archetype: one parent per table */
+            if (!it.src) continue;                      /* no parent: the Up term does not match this table */
+            uint32_t ps;
+            if (!ecs_has_id(s->world, it.src, s->world_id)) goto not_a_patch; /* Up resolves further up, or not at all */
+            if (it.src == s->root) it.level = 0;
+            else if (slot_lookup(s, it.src, &ps)) it.level = level_of_slot(s, ps) + 1;
+            else goto not_a_patch; /* a parent this system does not hold (a second root, a parent created just now) */
+            if ((uint32_t)it.level >= s->n_levels) goto not_a_patch; /* a level deeper than the scene has */
+        }
+        rows_in += it.count;
+        need[it.level] += it.count;
+        items[ni++] = it;
+    }
+    if (!ni) goto done;
+    for (uint32_t l = 0; l < s->n_levels; ++l)
+        if ((uint64_t)s->level_fill[l] + need[l] > s->level_begin[l + 1]) goto not_a_patch; /* the level's spare slots are used up */
+    if ((s->slot_entries + rows_in) * 10 > s->slot_of.cap * 7) goto not_a_patch;          /* the entity -> slot map is filling up */
+    if (rows_in > s->n_slots / 4) goto not_a_patch;                                       /* most of a level moves: a rebuild is cheaper */
+    /* an entity that leaves while batches still name it as their parent is not a leaf operation */
+    if (map_init(&incoming, rows_in + 8) != 0) {
+        rc = YH_ERR_OOM;
+        goto done;
+    }
+    for (uint32_t i = 0; i < ni; ++i) {
+        const ecs_entity_t* ents = items[i].count ? ecs_table_entities(items[i].table) : NULL;
+        for (uint32_t r = 0; r < items[i].count; ++r) {
+            map_put(&incoming, ents[r], 1);
+            /* a row that changes its level takes its whole subtree along: not a leaf operation either */
+            uint32_t os, cb;
+            if (!slot_lookup(s, ents[r], &os) || level_of_slot(s, os) == items[i].level || !map_get(&s->child_batches, ents[r], &cb)) continue;
+            for (; cb != UINT32_MAX; cb = s->next_child[cb])
+                if (s->batches[cb].count && s->batches[cb].src == ents[r]) goto not_a_patch;
+        }
+    }
+    for (uint32_t i = 0; i < ni; ++i) {
+        if (items[i].old_batch == UINT32_MAX) continue;
+        const Batch* b = &s->batches[items[i].old_batch];
+        for (uint32_t r = 0; r < b->count; ++r) {
+            const ecs_entity_t e = s->entity_of_slot[b->slot_begin + r];
+            uint32_t one, cb;
+            if (map_get(&incoming, e, &one) || !map_get(&s->child_batches, e, &cb)) continue;
+            for (; cb != UINT32_MAX; cb = s->next_child[cb])
+                if (s->batches[cb].count && s->batches[cb].src == e) goto not_a_patch;
+        }
+    }
+    /* room for the new batches */
+    if (s->n_batches + ni > s->cap_batches) {
+        uint32_t cap = s->cap_batches ? s->cap_batches : 256;
+        while (cap < s->n_batches + ni) cap *= 2;
+        Batch* nb = (Batch*)realloc(s->batches, cap * sizeof(Batch));
+        if (nb) s->batches = nb;
+        uint32_t* nc = (uint32_t*)realloc(s->next_child, cap * sizeof(uint32_t));
+        if (nc) s->next_child = nc;
+        if (!nb || !nc) {
+            rc = YH_ERR_OOM;
+            goto done;
+        }
+        s->cap_batches = cap;
+    }
+    if (s->batch_by_table.cap < ((uint64_t)s->n_batches + ni) * 2 || s->child_batches.cap < ((uint64_t)s->n_batches + ni) * 2) goto not_a_patch;
+
+    /* from here on the state changes: an error leaves it to the next frame's rebuild (the caller sees to that) */
+    for (uint32_t i = 0; i < ni; ++i) { /* the old slots die */
+        if (items[i].old_batch == UINT32_MAX) continue;
+        Batch* b = &s->batches[items[i].old_batch];
+        if ((rc = yh_scene_set_alive_range(s->scene, b->slot_begin, b->count, 0)) != YH_OK) goto done;
+        memset(s->entity_of_slot + b->slot_begin, 0, sizeof(ecs_entity_t) * b->count);
+        memset(s->batch_of + b->slot_begin, 0xFF, sizeof(uint32_t) * b->count);
+        s->n -= b->count;
+        b->count = 0;
+        b->table = NULL;
+        b->world_col = b->local_col = NULL;
+    }
+    qsort(items, ni, sizeof(PatchItem), by_level); /* (parents before children; equal levels in any order) */
+    for (uint32_t i = 0; i < ni; ++i) { /* the rows take spare slots of their level */
+        PatchItem* it = &items[i];
+        if (!it->count) continue;
+        const uint32_t bi = s->n_batches++, first = s->level_fill[it->level];
+        it->new_batch = bi;
+        s->level_fill[it->level] += it->count;
+        Batch* b = &s->batches[bi];
+        memset(b, 0, sizeof *b);
+        b->table = it->table;
+        b->col_w = it->col_w;
+        b->col_l = it->col_l;
+        b->src = it->src;
+        b->count = it->count;
+        b->slot_begin = first;
+        b->level = it->level;
+        b->world_col = ecs_table_get_column(it->table, it->col_w, 0);
+        b->local_col = ecs_table_get_column(it->table, it->col_l, 0);
+        link_batch(s, bi);
+        const ecs_entity_t* ents = ecs_table_entities(it->table);
+        memcpy(s->entity_of_slot + first, ents, sizeof(ecs_entity_t) * it->count);
+        for (uint32_t r = 0; r < it->count; ++r) {
+            map_put(&s->slot_of, ents[r], first + r);
+            s->batch_of[first + r] = bi;
+        }
+        s->slot_entries += it->count;
+        s->n += it->count;
+        /* rows as flecs holds them, flags included (a new entity's LocalTransform is dirty: transform.zig:46-51; a
+         * re-parented one keeps its flags: ecs.zig:470-477 sets none) */
+        if ((rc = yh_scene_set_alive_range(s->scene, first, it->count, 1)) != YH_OK ||
+            (rc = yh_upload_world_aos68(s->scene, b->world_col, first, it->count)) != YH_OK ||
+            (rc = yh_upload_local_aos68(s->scene, b->local_col, first, it->count)) != YH_OK)
+            goto done;
+        s->last_up_rows += 2u * it->count;
+        if (s->scene_bounds_kind == YH_BOUNDS_MESH_TABLE) {
+            s->bounds_stale = 1; /* mesh ids of the moved rows: the next upload_bounds reads them from their tables */
+        } else {
+            float* planes = (float*)calloc((size_t)it->count * 6, sizeof(float));
+            if (!planes) {
+                rc = YH_ERR_OOM;
+                goto done;
+            }
+            for (uint32_t r = 0; r < it->count && s->bounds_n; ++r) {
+                const BoundsEntry* be = bounds_find(s, ents[r]);
+                if (be)
+                    for (int k = 0; k < 6; ++k) planes[(size_t)k * it->count + r] = be->mm[k];
+            }
+            const float* mn[3] = {planes, planes + it->count, planes + 2 * (size_t)it->count};
+            const float* mx[3] = {planes + 3 * (size_t)it->count, planes + 4 * (size_t)it->count, planes + 5 * (size_t)it->count};
+            rc = yh_upload_aabb(s->scene, mn, mx, first, it->count);
+            free(planes);
+            if (rc != YH_OK) goto done;
+        }
+    }
+    for (uint32_t i = 0; i < ni; ++i) { /* parent slots: of the moved rows, and of the children of every moved row */
+        const PatchItem* it = &items[i];
+        if (!it->count) continue;
+        const Batch* b = &s->batches[it->new_batch];
+        uint32_t ps = YH_NO_PARENT;
+        if (b->level > 0 && !slot_lookup(s, b->src, &ps)) {
+            rc = YH_ERR_STATE;
+            goto done;
+        }
+        if ((rc = upload_parent_run(s, b->slot_begin, b->count, ps)) != YH_OK) goto done;
+        for (uint32_t r = 0; r < b->count; ++r) {
+            const ecs_entity_t e = s->entity_of_slot[b->slot_begin + r];
+            uint32_t cb;
+            if (!map_get(&s->child_batches, e, &cb)) continue;
+            for (; cb != UINT32_MAX; cb = s->next_child[cb]) {
+                const Batch* c = &s->batches[cb];
+                if (c->count && c->src == e && (rc = upload_parent_run(s, c->slot_begin, c->count, b->slot_begin + r)) != YH_OK) goto done;
+            }
+        }
+    }
+    s->patches += 1;
+    s->walk_cache_valid = 0; /* cached_* no longer describe the batches: whatever walks the query next rebuilds */
+done:
+    free(items);
+    free(incoming.e);
+    return rc;
+not_a_patch:
+    free(items);
+    free(incoming.e);
+    return 1;
+}
+
 static double now_ms(void) {
     struct timespec t;
     clock_gettime(CLOCK_MONOTONIC, &t);
@@ -922,13 +1241,39 @@ static double now_ms(void) {
 static void run(ecs_iter_t* it) {
     GpuTransformCullSystem* s = (GpuTransformCullSystem*)it->ctx;
     int rc = YH_OK;
+    uint64_t patched_rows_up = 0;
     const double t_begin = now_ms();
     memset(s->last_ms, 0, sizeof s->last_ms);
     int rebuilt = 0;
     /* Nothing structural happened since the batches were last brought up to date (no observer fired, the query's cache
      * matched or unmatched no table): they still are the world's tables, row for row.  No iteration, no validation. */
-    const int clean = s->skip_walks && s->trust_observers && !s->structure_dirty && s->scene && s->cached_n && s->batches_live &&
-                      it->query && ecs_query_match_count(it->query) == s->cached_match_count;
+    int clean = s->skip_walks && s->trust_observers && !s->structure_dirty && s->scene && s->cached_n && s->batches_live &&
+                it->query && ecs_query_match_count(it->query) == s->cached_match_count;
+    s->last_up_rows = 0;
+    s->last_patch_tables = 0;
+    if (!clean && s->patching && s->incremental && s->readback && !s->host_stale && s->skip_walks && s->trust_observers &&
+        !s->need_full && s->scene && s->cached_n && s->batches_live && it->query) {
+        /* rows entered or left a few tables: move just those (no walk of the query, no rebuild) */
+        const double t_patch = now_ms();
+        rc = patch(s);
+        s->last_ms[5] = now_ms() - t_patch;
+        if (rc == YH_OK) {
+            s->structure_dirty = 0;
+            s->n_touched = 0;
+            s->cached_match_count = ecs_query_match_count(it->query);
+            clean = 1;
+            patched_rows_up = s->last_up_rows;
+        } else if (rc < 0) { /* half-done: nothing of the cached state is trusted any more */
+            s->need_full = 1;
+            s->structure_dirty = 1;
+            s->walk_cache_valid = 0;
+            s->batches_live = 0;
+            ecs_iter_fini(it);
+            s->status = rc;
+            return;
+        }
+        rc = YH_OK;
+    }
     uint8_t* root_row = NULL;
     if (clean) {
         ecs_iter_fini(it); /* the iterator is not consumed */
@@ -937,6 +1282,8 @@ static void run(ecs_iter_t* it) {
     } else {
         s->batches_live = 0;
         s->structure_dirty = 0; /* (cleared first: what the walk below sees is what the flag stands for) */
+        s->n_touched = 0;
+        s->need_full = 0;
         if (s->skip_walks && restore_walk(s, it)) {
             ecs_iter_fini(it);
         } else {
@@ -1017,16 +1364,16 @@ static void run(ecs_iter_t* it) {
             memcpy(s->stage_w + (size_t)b->slot_begin * ROW, b->world_col, (size_t)b->count * ROW);
             memcpy(s->stage_l + (size_t)b->slot_begin * ROW, b->local_col, (size_t)b->count * ROW);
         }
-        if ((rc = yh_upload_world_aos68(s->scene, s->stage_w, 0, s->n)) != YH_OK ||
-            (rc = yh_upload_local_aos68(s->scene, s->stage_l, 0, s->n)) != YH_OK) {
+        if ((rc = yh_upload_world_aos68(s->scene, s->stage_w, 0, s->n_slots)) != YH_OK ||
+            (rc = yh_upload_local_aos68(s->scene, s->stage_l, 0, s->n_slots)) != YH_OK) {
             s->status = rc;
             return;
         }
-        s->last_up_rows = 2 * s->n;
+        s->last_up_rows = 2 * s->n_slots;
     } else {
         /* the rows whose onSet hook fired since the last frame (transform.zig:46-51, 92-97: the only writers of dirty) */
         s->epoch += 1;
-        s->last_up_rows = 0;
+        s->last_up_rows = patched_rows_up;
         for (int k = 0; k < 2; ++k) {
             uint8_t* stage = k == 0 ? s->stage_l : s->stage_w;
             const uint64_t m = gather_dirty(s, k, stage);
@@ -1054,15 +1401,15 @@ static void run(ecs_iter_t* it) {
         for (int k = 0; k < 2; ++k)
             for (uint64_t i = 0; i < s->n_dirty[k]; ++i) {
                 uint32_t slot;
-                if (!map_get(&s->slot_of, s->dirty[k][i], &slot)) continue;
+                if (!slot_lookup(s, s->dirty[k][i], &slot)) continue;
                 const Batch* b = batch_of_slot(s, slot);
                 ((uint8_t*)(k == 0 ? b->local_col : b->world_col))[(size_t)(slot - b->slot_begin) * ROW + 64] = 0;
             }
         s->host_stale = 1;
         s->last_down_rows = 0;
     } else if (!s->incremental || s->host_stale) {
-        if ((rc = yh_download_world_aos68(s->scene, s->stage_w, 0, s->n)) != YH_OK ||
-            (rc = yh_download_local_aos68(s->scene, s->stage_l, 0, s->n)) != YH_OK) {
+        if ((rc = yh_download_world_aos68(s->scene, s->stage_w, 0, s->n_slots)) != YH_OK ||
+            (rc = yh_download_local_aos68(s->scene, s->stage_l, 0, s->n_slots)) != YH_OK) {
             s->status = rc;
             return;
         }
@@ -1071,7 +1418,7 @@ static void run(ecs_iter_t* it) {
             memcpy(b->world_col, s->stage_w + (size_t)b->slot_begin * ROW, (size_t)b->count * ROW);
             memcpy(b->local_col, s->stage_l + (size_t)b->slot_begin * ROW, (size_t)b->count * ROW);
         }
-        s->last_down_rows = 2 * s->n;
+        s->last_down_rows = 2 * s->n_slots;
         s->host_stale = 0;
     } else {
         /* Every row the frame recomputed or found dirty, flags cleared; all other rows are as flecs holds them.  The two
@@ -1134,6 +1481,7 @@ ecs_entity_t GpuTransformCullSystem_registerTo(ecs_world_t* world, ecs_entity_t 
     s->trust_observers = 1;
     s->structure_dirty = 1;
     s->readback = 1;
+    s->patching = 1;
     {
         long cpus = sysconf(_SC_NPROCESSORS_ONLN);
         s->threads = cpus >= 16 ? 16 : (cpus > 1 ? (int)cpus : 1); /* placing rows is bound by memory latency: helpers overlap the misses */
@@ -1231,6 +1579,14 @@ int GpuTransformCullSystem_setIncremental(GpuTransformCullSystem* s, int on) {
     return YH_OK;
 }
 
+int GpuTransformCullSystem_setPatching(GpuTransformCullSystem* s, int on) {
+    if (!s) return YH_ERR_BAD_ARG;
+    s->patching = on != 0;
+    s->cached_n = 0; /* the next frame rebuilds: the slot order gains or loses its spare slots */
+    return YH_OK;
+}
+uint64_t GpuTransformCullSystem_patches(const GpuTransformCullSystem* s) { return s ? s->patches : 0; }
+
 int GpuTransformCullSystem_setSkipWalks(GpuTransformCullSystem* s, int on) {
     if (!s) return YH_ERR_BAD_ARG;
     s->skip_walks = on != 0;
@@ -1305,7 +1661,7 @@ int GpuTransformCullSystem_setReadback(GpuTransformCullSystem* s, int on) {
 int GpuTransformCullSystem_fetchWorld(GpuTransformCullSystem* s, ecs_entity_t entity, float matrix[16]) {
     if (!s || !matrix || !s->scene) return YH_ERR_BAD_ARG;
     uint32_t slot;
-    if (!s->slot_of.e || !map_get(&s->slot_of, entity, &slot)) return YH_ERR_BAD_ARG;
+    if (!slot_lookup(s, entity, &slot)) return YH_ERR_BAD_ARG;
     uint8_t row[ROW];
     const int rc = yh_download_world_aos68(s->scene, row, slot, 1);
     if (rc == YH_OK) memcpy(matrix, row, 64);
@@ -1364,5 +1720,10 @@ void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
         if (s->observers[k] && s->world) ecs_delete(s->world, s->observers[k]);
     if (s->slot_buf_pinned) yh_host_free(s->ctx, s->slot_buf);
     else free(s->slot_buf);
+    free(s->touched);
+    free(s->cached_slot);
+    free(s->batch_by_table.e);
+    free(s->child_batches.e);
+    free(s->next_child);
     free(s);
 }

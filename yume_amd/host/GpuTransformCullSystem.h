@@ -76,6 +76,17 @@ uint64_t GpuTransformCullSystem_rebuilds(const GpuTransformCullSystem* s);
 /* Incremental mode (on by default): only rows whose onSet fired are uploaded, only rows the frame touched are
  * downloaded.  Off: whole columns both ways every frame.  Switching costs one full upload. */
 int GpuTransformCullSystem_setIncremental(GpuTransformCullSystem* s, int on);
+/* Small structural changes without a rebuild (default on; incremental mode with readback only).  Entities created,
+ * deleted or re-parented between frames (editor/Editor.zig:590-636, GameApp.zig:204-215) change a few tables; the
+ * observers list them, and the next frame moves just their rows: every level's range of slots ends in spare slots
+ * (an eighth of the level, at least 64; dead on the device: yh_scene_set_alive_range), the rows of a table that changed
+ * take spare slots of its level, its old slots die, children of moved rows learn the new parent slot
+ * (yh_upload_parent_range).  No walk of the query, no re-sort, no column upload.  What is not a leaf operation - an
+ * entity with children deleted or moved to another depth, a new parent without a slot, a table deleted, a level's
+ * spare slots used up - falls back to the walk and the rebuild, which also compacts the slots again.
+ * `patches` counts the frames that took this path.                                                             */
+int GpuTransformCullSystem_setPatching(GpuTransformCullSystem* s, int on);
+uint64_t GpuTransformCullSystem_patches(const GpuTransformCullSystem* s);
 /* Walk-free frames (on by default): while the query's cache has not (un)matched a table and every matched table
  * still holds the entities it held, the per-frame iteration of the query (~0.3 us per table in flecs) is skipped and
  * the last walk's tables are reused.  walkStats: iterations done / frames that skipped it. */
@@ -107,7 +118,8 @@ int GpuTransformCullSystem_setThreads(GpuTransformCullSystem* s, int n);
 /* 68-byte rows that crossed PCIe in the last frame, each direction (both components counted). */
 /* Wall time of the last frame by stage, ms: [0] tables, root, bounds, frusta; [1] changed rows gathered and sent up;
  * [2] the device frame (yh_frame + wait); [3] changed rows brought down and placed in their tables; and, both inside
- * [0] and zero in a frame without structural change: [4] the walk of the query, [5] the rebuild of the slot order. */
+ * [0] and zero in a frame without structural change: [4] the walk of the query, [5] the rebuild of the slot order, or
+ * the patch that replaced both. */
 void GpuTransformCullSystem_lastTimes(const GpuTransformCullSystem* s, double ms[6]);
 void GpuTransformCullSystem_lastTraffic(const GpuTransformCullSystem* s, uint64_t* rows_up, uint64_t* rows_down);
 

@@ -41,6 +41,8 @@ extern fn GpuTransformCullSystem_entities(s: *const State) u64;
 extern fn GpuTransformCullSystem_levels(s: *const State) u32;
 extern fn GpuTransformCullSystem_rebuilds(s: *const State) u64;
 extern fn GpuTransformCullSystem_setIncremental(s: *State, on: c_int) c_int;
+extern fn GpuTransformCullSystem_setPatching(s: *State, on: c_int) c_int;
+extern fn GpuTransformCullSystem_patches(s: *const State) u64;
 extern fn GpuTransformCullSystem_setSkipWalks(s: *State, on: c_int) c_int;
 extern fn GpuTransformCullSystem_setTrustObservers(s: *State, on: c_int) c_int;
 extern fn GpuTransformCullSystem_setReadback(s: *State, on: c_int) c_int;
