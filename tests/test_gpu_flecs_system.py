@@ -280,3 +280,159 @@ def test_the_system_reads_cameras_and_mesh_bounds_from_the_ecs(oracle, tmp_path)
         # a Mesh set on an entity that has one moves no row (no rebuild); a first Mesh is an archetype move (rebuild)
         assert rebuilds == rebuilds_before + (1 if fi in (0, 4) else 0), f"frame {fi}: {rebuilds} rebuilds"
         rebuilds_before = rebuilds
+
+
+@pytest.mark.parametrize("seed,ecs_inputs",  # more seeds: YH_STRUCT_SEEDS=40
+                         [(k, k % 4 == 3) for k in range(int(os.environ.get("YH_STRUCT_SEEDS", "4")))])
+def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cpu_systems(oracle, tmp_path, seed, ecs_inputs):
+    """Editor traffic (Editor.zig:590-636, GameApp.zig:204-215): entities created (under old parents, under parents
+    created a frame earlier), leaves deleted, leaves and whole subtrees re-parented (same depth and other depths),
+    parents with children deleted, mixed with matrix edits, frame after frame.  The system patches what it can (no walk,
+    no rebuild) and rebuilds otherwise; either way every row and every visible set equals the CPU systems' - and a
+    burst of creations larger than a level's spare slots must fall back to the rebuild."""
+    rng = np.random.default_rng(1000 + seed)
+    n0, levels, extra = 20_000, 6, 1500
+    n = n0 + extra
+    lo0 = oracle.synth_level_offsets(n0, levels)
+    par0 = oracle.synth_parents(lo0)
+    lo = np.concatenate([lo0, [n]]).astype(np.uint32)  # the harness only sizes arrays with it
+    parent = np.concatenate([par0, np.full(extra, 0xFFFFFFFE, np.uint32)])  # the extra entities are created by edits
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo0[1])))
+    bounds = oracle.synth_aabb(n)
+    planes = np.concatenate([oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()[:1]])
+
+    def rnd_m(scale=5.0):
+        return oracle.compose(rng.uniform(-scale, scale, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+
+    # a host-side model of the tree, to pick legal edits
+    cur_parent = {e: (int(par0[e]) if par0[e] != 0xFFFFFFFF else -1) for e in range(n0)}
+    children = {}
+    for e, p in cur_parent.items():
+        children.setdefault(p, set()).add(e)
+    depth = {e: int(np.searchsorted(lo0, e, side="right") - 1) for e in range(n0)}
+    alive = set(range(n0))
+    next_new = n0
+    had_children = np.zeros(n0, bool)
+    had_children[par0[par0 != 0xFFFFFFFF]] = True
+
+    def subtree(e):
+        out, stack = [], [e]
+        while stack:
+            x = stack.pop()
+            out.append(x)
+            stack.extend(children.get(x, ()))
+        return out
+
+    def height(e):
+        return max(depth[x] for x in subtree(e)) - depth[e]
+
+    frames = [[], []]
+    n_frames = 26
+    for fi in range(2, n_frames):
+        edits = []
+        kind_of_frame = rng.integers(0, 8)
+        pool = np.array(sorted(alive))
+        if kind_of_frame == 0:  # matrix edits only
+            pass
+        elif kind_of_frame in (1, 2) and next_new + 40 <= n:  # create a few leaves; some under parents created last frame
+            for _ in range(int(rng.integers(1, 30))):
+                p = int(rng.choice(pool))
+                if depth[p] + 1 >= levels:
+                    continue
+                e = next_new
+                next_new += 1
+                edits.append((e, 6, reparent_arg(p)))
+                cur_parent[e], depth[e] = p, depth[p] + 1
+                children.setdefault(p, set()).add(e)
+                alive.add(e)
+        elif kind_of_frame == 3:  # delete leaves
+            leaves = [int(e) for e in rng.choice(pool, 60) if not children.get(int(e))]
+            for e in dict.fromkeys(leaves[:25]):
+                edits.append((e, 2, np.zeros(16, np.float32)))
+                children[cur_parent[e]].discard(e)
+                alive.discard(e)
+        elif kind_of_frame == 4:  # re-parent leaves to a parent of the same depth, and to other depths
+            for e in dict.fromkeys(int(x) for x in rng.choice(pool, 40)):
+                if children.get(e) or e not in alive:
+                    continue
+                p = int(rng.choice(pool))
+                if p == e or depth[p] + 1 >= levels or p not in alive:
+                    continue
+                edits.append((e, 3, reparent_arg(p)))
+                children[cur_parent[e]].discard(e)
+                cur_parent[e], depth[e] = p, depth[p] + 1
+                children.setdefault(p, set()).add(e)
+        elif kind_of_frame == 5:  # re-parent a subtree (not a leaf operation: the system must fall back)
+            # (SURVEY F5: the CPU systems visit tables in creation order and are parent-first only while every table of
+            # parents was created before the tables of their children; the subtree's root therefore moves into a table
+            # that exists since the scene was built - a parent with children of its own, no deeper than the old parent)
+            for _try in range(40):
+                e, p = int(rng.choice(pool)), int(rng.choice(pool))
+                if not children.get(e) or p in subtree(e) or depth[p] + 1 + height(e) >= levels:
+                    continue
+                if p >= n0 or not had_children[p] or depth[p] > depth[e] - 1 or depth[e] == 0:
+                    continue
+                edits.append((e, 3, reparent_arg(p)))
+                children[cur_parent[e]].discard(e)
+                shift = depth[p] + 1 - depth[e]
+                for x in subtree(e):
+                    depth[x] += shift
+                cur_parent[e] = p
+                children.setdefault(p, set()).add(e)
+                break
+        elif kind_of_frame == 6:  # delete a parent: its subtree goes with it (flecs' ChildOf cleanup)
+            for _try in range(20):
+                e = int(rng.choice(pool))
+                if not children.get(e) or depth[e] == 0:
+                    continue
+                edits.append((e, 2, np.zeros(16, np.float32)))
+                children[cur_parent[e]].discard(e)
+                for x in subtree(e):
+                    alive.discard(x)
+                break
+        elif next_new + 400 <= n:  # a burst of creations under ONE parent: more than the level's 64 spare slots may hold
+            p = int(rng.choice([x for x in pool if depth[int(x)] + 1 < levels]))
+            for _ in range(int(rng.integers(100, 400))):
+                e = next_new
+                next_new += 1
+                edits.append((e, 6, reparent_arg(p)))
+                cur_parent[e], depth[e] = p, depth[p] + 1
+                children.setdefault(p, set()).add(e)
+                alive.add(e)
+        pool = np.array(sorted(alive))
+        for e in np.unique(rng.choice(pool, int(rng.integers(0, 60)))):
+            edits.append((int(e), int(rng.integers(0, 2)), rnd_m()))
+        frames.append(edits)
+    frames.append([])
+
+    scene, out_c, out_g = tmp_path / "scene.bin", tmp_path / "cpu.bin", tmp_path / "gpu.bin"
+    write_scene(scene, lo, parent, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
+    subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
+    if ecs_inputs:
+        env["YFH_ECS_INPUTS"] = "1"
+    subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
+    cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
+    gpu = read_out(out_g, n, len(frames), 2 if ecs_inputs else planes.shape[0], oracle.T68, gpu=True)
+    patches = rebuilds = 0
+    for fi, ((cw, cl, _, rows, _), (gw, gl, g_rebuilds, g_rows, vis)) in enumerate(zip(cpu, gpu)):
+        stats = f"(rows up, rows down, walks, skipped, patches) = {vis[-1]}, rebuilds {g_rebuilds}, edits {[(e, k) for e, k, _ in frames[fi]][:6]}"
+        with np.errstate(all="ignore"):
+            bad = np.flatnonzero(~np.all((gw["m"] == cw["m"]) | (np.isnan(gw["m"]) & np.isnan(cw["m"])), axis=1))
+            assert bad.size == 0, f"frame {fi}: {bad.size} world matrices differ, first rows {bad[:8]} {stats}"
+            assert np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi}: local matrices {stats}"
+        assert np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"]), f"frame {fi}: dirty bytes {stats}"
+        assert g_rows == rows, f"frame {fi}: {g_rows} rows on the device, {rows} in the CPU systems {stats}"
+        structural = any(kind in (2, 3, 6) for _e, kind, _m in frames[fi])
+        d_patch, d_rebuild = vis[-1][4] - patches, g_rebuilds - rebuilds
+        patches, rebuilds = vis[-1][4], g_rebuilds
+        if fi and structural:
+            assert d_patch + d_rebuild == 1, f"frame {fi}: a structural change is either patched or rebuilt {stats}"
+        elif fi:
+            assert d_patch == d_rebuild == 0, f"frame {fi}: nothing structural happened {stats}"
+        if not ecs_inputs:
+            here = np.flatnonzero(cw["m"].any(axis=1) | cl["m"].any(axis=1))  # rows of entities that exist
+            exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[here]), np.ascontiguousarray(bounds[here]), planes)
+            for f in range(planes.shape[0]):
+                assert np.array_equal(np.sort(vis[f]), here[np.flatnonzero(exp_vis[f])]), f"frame {fi} frustum {f}: visible set {stats}"
+    assert patches >= 3 and rebuilds >= 2, f"the script was meant to exercise both paths: {patches} patches, {rebuilds} rebuilds"
