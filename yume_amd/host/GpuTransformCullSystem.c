@@ -149,9 +149,6 @@ struct GpuTransformCullSystem {
     int need_full;                /* an event patch() cannot follow: a table deleted, too many tables touched */
     int walk_cache_valid;         /* cached_* describe the batches (false after a patch: the next walk rebuilds) */
     uint32_t* cached_slot;        /* per batch: slot_begin as the last rebuild assigned it */
-    Map batch_by_table;           /* table -> index into batches[] */
-    Map child_batches;            /* entity -> first batch whose rows have it as their parent */
-    uint32_t* next_child;         /* per batch: next batch with the same parent (UINT32_MAX: none) */
     uint64_t slot_entries;        /* entries put into slot_of (stale ones stay until the next rebuild) */
     uint64_t patches, last_patch_tables;
 
@@ -304,18 +301,6 @@ static void free_stage(GpuTransformCullSystem* s) {
     }
     s->stage_w = s->stage_l = NULL;
     s->pinned = 0;
-}
-
-/* table -> batch, parent -> batches of its children (lists through next_child) */
-static void link_batch(GpuTransformCullSystem* s, uint32_t b) {
-    const Batch* bt = &s->batches[b];
-    if (bt->table) map_put(&s->batch_by_table, (ecs_entity_t)(uintptr_t)bt->table, b);
-    uint32_t head = UINT32_MAX;
-    if (bt->src) {
-        (void)map_get(&s->child_batches, bt->src, &head);
-        map_put(&s->child_batches, bt->src, b);
-    }
-    s->next_child[b] = head;
 }
 
 /* ---- rebuild of the slot order ----------------------------------------------------------------------------- */
@@ -504,17 +489,6 @@ static int rebuild(GpuTransformCullSystem* s) {
         rc = YH_ERR_OOM;
         goto done;
     }
-    /* table -> batch and parent -> batches of its children, for patch() */
-    free(s->batch_by_table.e);
-    free(s->child_batches.e);
-    free(s->next_child);
-    s->batch_by_table.e = s->child_batches.e = NULL;
-    s->next_child = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(s->cap_batches ? s->cap_batches : 1));
-    if (!s->next_child || map_init(&s->batch_by_table, (uint64_t)nb + 1024) != 0 || map_init(&s->child_batches, (uint64_t)nb + 1024) != 0) {
-        rc = YH_ERR_OOM;
-        goto done;
-    }
-    for (uint32_t b = 0; b < nb; ++b) link_batch(s, b);
     if ((rc = yh_scene_track_changes(s->scene, s->incremental)) != YH_OK) goto done;
 
     /* remember this walk */
@@ -1032,7 +1006,8 @@ static int upload_parent_run(GpuTransformCullSystem* s, uint32_t first, uint32_t
 /* The tables the observers listed are compared with their batches; the rows of one that changed (entities created in
  * it, deleted from it, moved in or out by a re-parenting or by an unrelated component) move to spare slots of its
  * level, its old slots die, the children of every row that moved learn their parent's new slot.  Nothing else is
- * touched: no query walk, no re-sort, no column upload beyond the moved rows.
+ * touched: no query walk, no re-sort, no column upload beyond the moved rows; the cost is two passes over the batch
+ * table (which table is whose batch, which batches are children of a moved row) plus the moved rows.
  * Returns YH_OK (the batches follow the world again), 1 (not a case for a patch: walk and rebuild), or an error. */
 static int patch(GpuTransformCullSystem* s) {
     int rc = YH_OK;
@@ -1045,21 +1020,38 @@ static int patch(GpuTransformCullSystem* s) {
     s->last_patch_tables = nt;
     if (!nt) return YH_OK;
     PatchItem* items = (PatchItem*)calloc(nt, sizeof(PatchItem));
-    Map incoming = {0}; /* entities of the tables' new contents */
+    uint32_t* old_of = (uint32_t*)malloc(sizeof(uint32_t) * nt); /* per listed table: its batch, or UINT32_MAX */
+    uint32_t* kids = NULL;  /* batches whose parent is a row that moves or leaves */
+    uint32_t n_kids = 0, cap_kids = 0;
+    Map moved = {0}; /* entity -> 1 + index of the item whose new content holds it, 0: it leaves */
     uint64_t rows_in = 0, rows_out = 0, need[YH_MAX_LEVELS];
     uint32_t ni = 0;
     memset(need, 0, sizeof need);
-    if (!items) return YH_ERR_OOM;
+    if (!items || !old_of) {
+        rc = YH_ERR_OOM;
+        goto done;
+    }
+    /* which listed table is which batch: one pass over the batches, a binary search each */
+    memset(old_of, 0xFF, sizeof(uint32_t) * nt);
+    for (uint32_t b = 0; b < s->n_batches; ++b) {
+        const Batch* bt = &s->batches[b];
+        if (!bt->count || !bt->table) continue;
+        uint32_t lo = 0, hi = nt;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) / 2;
+            if ((uintptr_t)s->touched[mid] < (uintptr_t)bt->table) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < nt && s->touched[lo] == bt->table) old_of[lo] = b;
+    }
     /* what every listed table holds now, and where its rows belong */
     for (uint32_t i = 0; i < nt; ++i) {
         ecs_table_t* t = s->touched[i];
         PatchItem it;
         memset(&it, 0, sizeof it);
         it.table = t;
-        it.old_batch = it.new_batch = UINT32_MAX;
-        uint32_t ob;
-        if (map_get(&s->batch_by_table, (ecs_entity_t)(uintptr_t)t, &ob) && ob < s->n_batches && s->batches[ob].table == t && s->batches[ob].count)
-            it.old_batch = ob;
+        it.old_batch = old_of[i];
+        it.new_batch = UINT32_MAX;
         it.col_w = ecs_table_get_column_index(s->world, t, s->world_id);
         it.col_l = ecs_table_get_column_index(s->world, t, s->local_id);
         it.count = it.col_w >= 0 && it.col_l >= 0 ? (uint32_t)ecs_table_count(t) : 0u;
@@ -1091,48 +1083,53 @@ static int patch(GpuTransformCullSystem* s) {
         if ((uint64_t)s->level_fill[l] + need[l] > s->level_begin[l + 1]) goto not_a_patch; /* the level's spare slots are used up */
     if ((s->slot_entries + rows_in) * 10 > s->slot_of.cap * 7) goto not_a_patch;          /* the entity -> slot map is filling up */
     if (rows_in > s->n_slots / 4) goto not_a_patch;                                       /* most of a level moves: a rebuild is cheaper */
-    /* an entity that leaves while batches still name it as their parent is not a leaf operation */
-    if (map_init(&incoming, rows_in + 8) != 0) {
+    /* the rows that move or leave, and the batches that name one of them as their parent */
+    if (map_init(&moved, rows_in + rows_out + 8) != 0) {
         rc = YH_ERR_OOM;
         goto done;
     }
     for (uint32_t i = 0; i < ni; ++i) {
-        const ecs_entity_t* ents = items[i].count ? ecs_table_entities(items[i].table) : NULL;
-        for (uint32_t r = 0; r < items[i].count; ++r) {
-            map_put(&incoming, ents[r], 1);
-            /* a row that changes its level takes its whole subtree along: not a leaf operation either */
-            uint32_t os, cb;
-            if (!slot_lookup(s, ents[r], &os) || level_of_slot(s, os) == items[i].level || !map_get(&s->child_batches, ents[r], &cb)) continue;
-            for (; cb != UINT32_MAX; cb = s->next_child[cb])
-                if (s->batches[cb].count && s->batches[cb].src == ents[r]) goto not_a_patch;
-        }
-    }
-    for (uint32_t i = 0; i < ni; ++i) {
         if (items[i].old_batch == UINT32_MAX) continue;
         const Batch* b = &s->batches[items[i].old_batch];
-        for (uint32_t r = 0; r < b->count; ++r) {
-            const ecs_entity_t e = s->entity_of_slot[b->slot_begin + r];
-            uint32_t one, cb;
-            if (map_get(&incoming, e, &one) || !map_get(&s->child_batches, e, &cb)) continue;
-            for (; cb != UINT32_MAX; cb = s->next_child[cb])
-                if (s->batches[cb].count && s->batches[cb].src == e) goto not_a_patch;
+        for (uint32_t r = 0; r < b->count; ++r) map_put(&moved, s->entity_of_slot[b->slot_begin + r], 0);
+    }
+    for (uint32_t i = 0; i < ni; ++i) {
+        const ecs_entity_t* ents = items[i].count ? ecs_table_entities(items[i].table) : NULL;
+        for (uint32_t r = 0; r < items[i].count; ++r) map_put(&moved, ents[r], 1 + i);
+    }
+    for (uint32_t b = 0; b < s->n_batches; ++b) {
+        const Batch* bt = &s->batches[b];
+        uint32_t where;
+        if (!bt->count || !bt->src || !map_get(&moved, bt->src, &where)) continue;
+        /* an entity that leaves while batches still name it as their parent, or a row that changes its level and so
+         * takes its whole subtree along: not leaf operations */
+        if (!where) goto not_a_patch;
+        uint32_t os;
+        if (slot_lookup(s, bt->src, &os) && level_of_slot(s, os) != items[where - 1].level) goto not_a_patch;
+        if (n_kids == cap_kids) {
+            const uint32_t cap = cap_kids ? cap_kids * 2 : 64;
+            uint32_t* g = (uint32_t*)realloc(kids, sizeof(uint32_t) * cap);
+            if (!g) {
+                rc = YH_ERR_OOM;
+                goto done;
+            }
+            kids = g;
+            cap_kids = cap;
         }
+        kids[n_kids++] = b;
     }
     /* room for the new batches */
     if (s->n_batches + ni > s->cap_batches) {
         uint32_t cap = s->cap_batches ? s->cap_batches : 256;
         while (cap < s->n_batches + ni) cap *= 2;
         Batch* nb = (Batch*)realloc(s->batches, cap * sizeof(Batch));
-        if (nb) s->batches = nb;
-        uint32_t* nc = (uint32_t*)realloc(s->next_child, cap * sizeof(uint32_t));
-        if (nc) s->next_child = nc;
-        if (!nb || !nc) {
+        if (!nb) {
             rc = YH_ERR_OOM;
             goto done;
         }
+        s->batches = nb;
         s->cap_batches = cap;
     }
-    if (s->batch_by_table.cap < ((uint64_t)s->n_batches + ni) * 2 || s->child_batches.cap < ((uint64_t)s->n_batches + ni) * 2) goto not_a_patch;
 
     /* from here on the state changes: an error leaves it to the next frame's rebuild (the caller sees to that) */
     for (uint32_t i = 0; i < ni; ++i) { /* the old slots die */
@@ -1164,7 +1161,6 @@ static int patch(GpuTransformCullSystem* s) {
         b->level = it->level;
         b->world_col = ecs_table_get_column(it->table, it->col_w, 0);
         b->local_col = ecs_table_get_column(it->table, it->col_l, 0);
-        link_batch(s, bi);
         const ecs_entity_t* ents = ecs_table_entities(it->table);
         memcpy(s->entity_of_slot + first, ents, sizeof(ecs_entity_t) * it->count);
         for (uint32_t r = 0; r < it->count; ++r) {
@@ -1200,7 +1196,7 @@ static int patch(GpuTransformCullSystem* s) {
             if (rc != YH_OK) goto done;
         }
     }
-    for (uint32_t i = 0; i < ni; ++i) { /* parent slots: of the moved rows, and of the children of every moved row */
+    for (uint32_t i = 0; i < ni; ++i) { /* parent slots of the moved rows (their parent may have moved in this patch too) */
         const PatchItem* it = &items[i];
         if (!it->count) continue;
         const Batch* b = &s->batches[it->new_batch];
@@ -1210,25 +1206,30 @@ static int patch(GpuTransformCullSystem* s) {
             goto done;
         }
         if ((rc = upload_parent_run(s, b->slot_begin, b->count, ps)) != YH_OK) goto done;
-        for (uint32_t r = 0; r < b->count; ++r) {
-            const ecs_entity_t e = s->entity_of_slot[b->slot_begin + r];
-            uint32_t cb;
-            if (!map_get(&s->child_batches, e, &cb)) continue;
-            for (; cb != UINT32_MAX; cb = s->next_child[cb]) {
-                const Batch* c = &s->batches[cb];
-                if (c->count && c->src == e && (rc = upload_parent_run(s, c->slot_begin, c->count, b->slot_begin + r)) != YH_OK) goto done;
-            }
+    }
+    for (uint32_t k = 0; k < n_kids; ++k) { /* and of the children of every moved row */
+        const Batch* c = &s->batches[kids[k]];
+        uint32_t ps;
+        if (!c->count) continue; /* (a child batch that was itself listed: moved above, with its parent's new slot) */
+        if (!slot_lookup(s, c->src, &ps)) {
+            rc = YH_ERR_STATE;
+            goto done;
         }
+        if ((rc = upload_parent_run(s, c->slot_begin, c->count, ps)) != YH_OK) goto done;
     }
     s->patches += 1;
     s->walk_cache_valid = 0; /* cached_* no longer describe the batches: whatever walks the query next rebuilds */
 done:
     free(items);
-    free(incoming.e);
+    free(old_of);
+    free(kids);
+    free(moved.e);
     return rc;
 not_a_patch:
     free(items);
-    free(incoming.e);
+    free(old_of);
+    free(kids);
+    free(moved.e);
     return 1;
 }
 
@@ -1722,8 +1723,5 @@ void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     else free(s->slot_buf);
     free(s->touched);
     free(s->cached_slot);
-    free(s->batch_by_table.e);
-    free(s->child_batches.e);
-    free(s->next_child);
     free(s);
 }
