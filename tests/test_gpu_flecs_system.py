@@ -415,6 +415,15 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
     cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
     gpu = read_out(out_g, n, len(frames), 2 if ecs_inputs else planes.shape[0], oracle.T68, gpu=True)
     patches = rebuilds = 0
+    cull_bounds, cull_planes = bounds, planes
+    if ecs_inputs:  # the harness' Mesh components (entity e: mesh e % 4, none for 0) and its two Camera entities
+        from yume_amd import synth
+
+        box = {0: [0, 0, 0, 0, 0, 0]}
+        for k in (1, 2, 3):
+            box[k] = [-0.5 * k, -0.25 * k - 0.5, -1.0, 0.5 * k, 0.25 * k + 0.5, 1.5]
+        cull_bounds = np.array([box[e % 4] for e in range(n)], np.float32)
+        cull_planes = np.stack([synth.main_camera_planes(), synth.cascade_planes()[1]]).astype(np.float32).reshape(2, 24)
     for fi, ((cw, cl, _, rows, _), (gw, gl, g_rebuilds, g_rows, vis)) in enumerate(zip(cpu, gpu)):
         stats = f"(rows up, rows down, walks, skipped, patches) = {vis[-1]}, rebuilds {g_rebuilds}, edits {[(e, k) for e, k, _ in frames[fi]][:6]}"
         with np.errstate(all="ignore"):
@@ -430,9 +439,8 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
             assert d_patch + d_rebuild == 1, f"frame {fi}: a structural change is either patched or rebuilt {stats}"
         elif fi:
             assert d_patch == d_rebuild == 0, f"frame {fi}: nothing structural happened {stats}"
-        if not ecs_inputs:
-            here = np.flatnonzero(cw["m"].any(axis=1) | cl["m"].any(axis=1))  # rows of entities that exist
-            exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[here]), np.ascontiguousarray(bounds[here]), planes)
-            for f in range(planes.shape[0]):
-                assert np.array_equal(np.sort(vis[f]), here[np.flatnonzero(exp_vis[f])]), f"frame {fi} frustum {f}: visible set {stats}"
+        here = np.flatnonzero(cw["m"].any(axis=1) | cl["m"].any(axis=1))  # rows of entities that exist
+        exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[here]), np.ascontiguousarray(cull_bounds[here]), cull_planes)
+        for f in range(cull_planes.shape[0]):
+            assert np.array_equal(np.sort(vis[f]), here[np.flatnonzero(exp_vis[f])]), f"frame {fi} frustum {f}: visible set {stats}"
     assert patches >= 3 and rebuilds >= 2, f"the script was meant to exercise both paths: {patches} patches, {rebuilds} rebuilds"

@@ -108,6 +108,10 @@ struct GpuTransformCullSystem {
     int32_t mesh_vertices_offset;
     uint32_t scene_bounds_kind;               /* bounds kind the device scene was created with */
     uint32_t n_meshes;                        /* entries of the mesh table of the last upload (entry 0: the empty box) */
+    float* mesh_table;                        /* host copy of the table: MESH_TABLE_MAX x {mins, maxs} */
+    uint32_t* mesh_vcount;
+    Map mesh_index;                           /* mesh pointer -> table entry */
+    uint32_t mesh_count;                      /* entries of the host copy (patch() appends; n_meshes follows at the next upload) */
 
     /* incremental mode: only rows whose onSet fired go up, only rows the frame touched come back */
     int incremental;
@@ -445,9 +449,13 @@ static int rebuild(GpuTransformCullSystem* s) {
             rc = YH_ERR_OOM;
             goto done;
         }
-        memset(s->stage_w, 0, (size_t)N * ROW); /* the rows of spare slots travel with the whole columns: defined bytes */
-        memset(s->stage_l, 0, (size_t)N * ROW);
     }
+    if (spare_slots) /* the rows of spare slots travel with the whole columns: defined bytes */
+        for (uint32_t lvl = 0; lvl < n_levels; ++lvl) {
+            const size_t first = (size_t)s->level_fill[lvl] * ROW, bytes = (size_t)(level_offsets[lvl + 1] - s->level_fill[lvl]) * ROW;
+            memset(s->stage_w + first, 0, bytes);
+            memset(s->stage_l + first, 0, bytes);
+        }
     s->n_slots = N;
     if ((rc = yh_upload_hierarchy(s->scene, parent_index, level_offsets)) != YH_OK) goto done;
     if (spare_slots) { /* (a scene that is reused may carry the dead slots of earlier patches) */
@@ -540,77 +548,95 @@ done:
     return rc;
 }
 
-/* Bounds from the Mesh component (engine/components/mesh.zig: `Mesh{ ref: *meshes.Mesh }`; the AABB is
- * meshes.Mesh.bounds, engine/meshes.zig:72-95, 104-110): one table entry per distinct mesh, entry 0 the empty box of
- * entities that have none, a u32 id per entity.  setBounds overrides get entries of their own.  Tables are walked
- * column-wise: one pointer compare per row, one hash lookup per run of rows that share a mesh. */
-static int upload_bounds_from_meshes(GpuTransformCullSystem* s) {
-    const uint64_t n = s->n_slots;
-    int rc = YH_OK;
-    uint32_t* ids = (uint32_t*)calloc((size_t)(n ? n : 1), sizeof(uint32_t));
-    float* table = (float*)calloc((size_t)MESH_TABLE_MAX * 6, sizeof(float));
-    uint32_t* vcount = (uint32_t*)calloc((size_t)MESH_TABLE_MAX, sizeof(uint32_t));
-    Map index_of = {0};
-    uint32_t n_meshes = 1; /* entry 0: no mesh = an empty box at the origin */
-    if (!ids || !table || !vcount || map_init(&index_of, 4096) != 0) {
-        rc = YH_ERR_OOM;
-        goto done;
+/* (the mesh table is kept on the host between uploads: patch() appends to it) */
+static int mesh_table_reset(GpuTransformCullSystem* s) {
+    if (!s->mesh_table) s->mesh_table = (float*)malloc(sizeof(float) * 6 * (size_t)MESH_TABLE_MAX);
+    if (!s->mesh_vcount) s->mesh_vcount = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)MESH_TABLE_MAX);
+    free(s->mesh_index.e);
+    s->mesh_index.e = NULL;
+    if (!s->mesh_table || !s->mesh_vcount || map_init(&s->mesh_index, 4096) != 0) return YH_ERR_OOM;
+    memset(s->mesh_table, 0, sizeof(float) * 6); /* entry 0: no mesh = an empty box at the origin */
+    s->mesh_vcount[0] = 0;
+    s->mesh_count = 1;
+    return YH_OK;
+}
+static int mesh_table_append(GpuTransformCullSystem* s, const float mm[6], uint32_t vertices, uint32_t* id) {
+    if (s->mesh_count == MESH_TABLE_MAX) return YH_ERR_CAPACITY;
+    *id = s->mesh_count++;
+    memcpy(s->mesh_table + 6 * (size_t)*id, mm, 24);
+    s->mesh_vcount[*id] = vertices;
+    return YH_OK;
+}
+/* table entry of the mesh a Mesh{ref} points to: looked up, or appended from the mesh's BoundingBox{mins, maxs} */
+static int mesh_table_entry(GpuTransformCullSystem* s, const uint8_t* mesh, uint32_t* id) {
+    if (map_get(&s->mesh_index, (ecs_entity_t)(uintptr_t)mesh, id)) return YH_OK;
+    if (s->mesh_index.cap < (uint64_t)s->mesh_count * 2 + 2) {
+        Map bigger = {0};
+        if (map_init(&bigger, s->mesh_index.cap) != 0) return YH_ERR_OOM; /* (map_init doubles what it is asked for) */
+        for (uint64_t q = 0; q < s->mesh_index.cap; ++q)
+            if (s->mesh_index.e[q].key) map_put(&bigger, s->mesh_index.e[q].key, s->mesh_index.e[q].value);
+        free(s->mesh_index.e);
+        s->mesh_index = bigger;
     }
-    for (uint32_t bi = 0; bi < s->n_batches && rc == YH_OK; ++bi) {
-        const Batch* b = &s->batches[bi];
-        if (!b->table) continue;
-        const int32_t col = ecs_table_get_column_index(s->world, b->table, s->mesh_id);
-        if (col < 0) continue;
+    float mm[6];
+    uint32_t vertices = 0;
+    memcpy(mm, mesh + s->mesh_bounds_offset, 24);
+    if (s->mesh_vertices_offset >= 0) {
+        uint64_t vc;
+        memcpy(&vc, mesh + s->mesh_vertices_offset, 8); /* vertices_count: usize */
+        vertices = vc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vc;
+    }
+    const int rc = mesh_table_append(s, mm, vertices, id);
+    if (rc == YH_OK) map_put(&s->mesh_index, (ecs_entity_t)(uintptr_t)mesh, *id);
+    return rc;
+}
+/* mesh ids of one batch's rows into ids[0 .. count): the Mesh column where the table has one, 0 elsewhere, an entry of
+ * its own for an entity with setBounds */
+static int mesh_ids_of_batch(GpuTransformCullSystem* s, const Batch* b, uint32_t* ids) {
+    memset(ids, 0, sizeof(uint32_t) * b->count);
+    const int32_t col = b->table ? ecs_table_get_column_index(s->world, b->table, s->mesh_id) : -1;
+    if (col >= 0) {
         const uint8_t* const* refs = (const uint8_t* const*)ecs_table_get_column(b->table, col, 0);
         const uint8_t* prev = NULL;
         uint32_t prev_id = 0;
-        for (uint32_t r = 0; r < b->count; ++r) {
+        for (uint32_t r = 0; r < b->count; ++r) { /* one hash lookup per run of rows that share a mesh */
             const uint8_t* mesh = refs[r];
             if (!mesh) continue;
             if (mesh != prev) {
-                uint32_t id;
-                if (!map_get(&index_of, (ecs_entity_t)(uintptr_t)mesh, &id)) {
-                    if (n_meshes == MESH_TABLE_MAX || index_of.cap < (uint64_t)n_meshes * 2 + 2) { /* (map sized for 4096 x 2) */
-                        if (n_meshes == MESH_TABLE_MAX) {
-                            rc = YH_ERR_CAPACITY;
-                            break;
-                        }
-                        Map bigger = {0};
-                        if (map_init(&bigger, index_of.cap) != 0) {
-                            rc = YH_ERR_OOM;
-                            break;
-                        }
-                        for (uint64_t q = 0; q < index_of.cap; ++q)
-                            if (index_of.e[q].key) map_put(&bigger, index_of.e[q].key, index_of.e[q].value);
-                        free(index_of.e);
-                        index_of = bigger;
-                    }
-                    id = n_meshes++;
-                    memcpy(table + 6 * (size_t)id, mesh + s->mesh_bounds_offset, 24); /* BoundingBox{mins, maxs} */
-                    if (s->mesh_vertices_offset >= 0) {
-                        uint64_t vc;
-                        memcpy(&vc, mesh + s->mesh_vertices_offset, 8); /* vertices_count: usize */
-                        vcount[id] = vc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vc;
-                    }
-                    map_put(&index_of, (ecs_entity_t)(uintptr_t)mesh, id);
-                }
+                const int rc = mesh_table_entry(s, mesh, &prev_id);
+                if (rc != YH_OK) return rc;
                 prev = mesh;
-                prev_id = id;
             }
-            ids[b->slot_begin + r] = prev_id;
+            ids[r] = prev_id;
         }
     }
-    if (rc == YH_OK && s->bounds_n) /* per-entity overrides */
-        for (uint64_t e = 0; e < n && rc == YH_OK; ++e) {
-            const BoundsEntry* o = s->entity_of_slot[e] ? bounds_find(s, s->entity_of_slot[e]) : NULL;
-            if (!o) continue;
-            if (n_meshes == MESH_TABLE_MAX) {
-                rc = YH_ERR_CAPACITY;
-                break;
-            }
-            memcpy(table + 6 * (size_t)n_meshes, o->mm, 24);
-            ids[e] = n_meshes++;
-        }
+    for (uint32_t r = 0; r < b->count && s->bounds_n; ++r) { /* per-entity overrides */
+        const BoundsEntry* o = bounds_find(s, s->entity_of_slot[b->slot_begin + r]);
+        if (!o) continue;
+        const int rc = mesh_table_append(s, o->mm, 0, &ids[r]);
+        if (rc != YH_OK) return rc;
+    }
+    return YH_OK;
+}
+static int mesh_table_upload(GpuTransformCullSystem* s) {
+    int rc = yh_upload_mesh_aabbs(s->scene, s->mesh_table, s->mesh_count);
+    if (rc == YH_OK && s->mesh_vertices_offset >= 0) rc = yh_upload_vertex_counts(s->scene, s->mesh_vcount, s->mesh_count);
+    if (rc == YH_OK) s->n_meshes = s->mesh_count;
+    return rc;
+}
+
+/* Bounds from the Mesh component (engine/components/mesh.zig: `Mesh{ ref: *meshes.Mesh }`; the AABB is
+ * meshes.Mesh.bounds, engine/meshes.zig:72-95, 104-110): one table entry per distinct mesh, entry 0 the empty box of
+ * entities that have none, a u32 id per entity.  setBounds overrides get entries of their own. */
+static int upload_bounds_from_meshes(GpuTransformCullSystem* s) {
+    const uint64_t n = s->n_slots;
+    int rc = mesh_table_reset(s);
+    uint32_t* ids = (uint32_t*)calloc((size_t)(n ? n : 1), sizeof(uint32_t));
+    if (!ids) rc = YH_ERR_OOM;
+    for (uint32_t bi = 0; bi < s->n_batches && rc == YH_OK; ++bi) {
+        const Batch* b = &s->batches[bi];
+        if (b->table && b->count) rc = mesh_ids_of_batch(s, b, ids + b->slot_begin);
+    }
     if (rc != YH_OK) goto done;
     /* ids first while they are all 0 .. old table, then the table, then the ids (the table may not shrink below an
      * id in use): zero ids are valid for every table */
@@ -623,18 +649,11 @@ static int upload_bounds_from_meshes(GpuTransformCullSystem* s) {
         rc = s->n_meshes ? yh_upload_mesh_ids(s->scene, zero, 0, n) : YH_OK;
         free(zero);
     }
-    if (rc == YH_OK) rc = yh_upload_mesh_aabbs(s->scene, table, n_meshes);
+    if (rc == YH_OK) rc = mesh_table_upload(s);
     if (rc == YH_OK) rc = yh_upload_mesh_ids(s->scene, ids, 0, n);
-    if (rc == YH_OK && s->mesh_vertices_offset >= 0) rc = yh_upload_vertex_counts(s->scene, vcount, n_meshes);
-    if (rc == YH_OK) {
-        s->n_meshes = n_meshes;
-        s->bounds_stale = 0;
-    }
+    if (rc == YH_OK) s->bounds_stale = 0;
 done:
     free(ids);
-    free(table);
-    free(vcount);
-    free(index_of.e);
     return rc;
 }
 
@@ -1177,7 +1196,17 @@ static int patch(GpuTransformCullSystem* s) {
             goto done;
         s->last_up_rows += 2u * it->count;
         if (s->scene_bounds_kind == YH_BOUNDS_MESH_TABLE) {
-            s->bounds_stale = 1; /* mesh ids of the moved rows: the next upload_bounds reads them from their tables */
+            if (s->bounds_stale || !s->mesh_index.e) continue; /* every id is about to be read afresh anyway */
+            /* mesh ids of the moved rows; a mesh seen for the first time extends the table (which goes up first) */
+            const uint32_t had = s->mesh_count;
+            if ((rc = mesh_ids_of_batch(s, b, s->slot_buf)) != YH_OK) {
+                if (rc != YH_ERR_CAPACITY) goto done;
+                s->bounds_stale = 1; /* the table is full of entries nobody uses any more: the full upload compacts it */
+                rc = YH_OK;
+                continue;
+            }
+            if (s->mesh_count != had && (rc = mesh_table_upload(s)) != YH_OK) goto done;
+            if ((rc = yh_upload_mesh_ids(s->scene, s->slot_buf, first, it->count)) != YH_OK) goto done;
         } else {
             float* planes = (float*)calloc((size_t)it->count * 6, sizeof(float));
             if (!planes) {
@@ -1722,6 +1751,9 @@ void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     if (s->slot_buf_pinned) yh_host_free(s->ctx, s->slot_buf);
     else free(s->slot_buf);
     free(s->touched);
+    free(s->mesh_table);
+    free(s->mesh_vcount);
+    free(s->mesh_index.e);
     free(s->cached_slot);
     free(s);
 }
