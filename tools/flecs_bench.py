@@ -38,14 +38,16 @@ with tempfile.TemporaryDirectory() as d:
                                ("GPU system, incremental, every table validated every frame (round 1)", GPU, {"YFH_VALIDATE": "1"}),
                                ("GPU system, incremental, 1 thread copies rows back", GPU, {"YFH_THREADS": "1"}),
                                ("GPU system, incremental", GPU, {}),
+                               ("GPU system, incremental, every structural change rebuilt (setPatching(0))", GPU, {"YFH_NO_PATCH": "1"}),
+                               ("GPU system, incremental, cameras and mesh bounds read from the ECS", GPU, {"YFH_ECS_INPUTS": "1"}),
                                ("GPU system, incremental, results stay on the device (last frame reads all back)", GPU, {"YFH_NO_READBACK": "1"})):
         e = dict(os.environ, YFH_TIMES="1", **env)
-        for k in ("YFH_PLAIN", "YFH_VALIDATE", "YFH_ALWAYS_WALK", "YFH_NO_READBACK", "YFH_THREADS"):
+        for k in ("YFH_PLAIN", "YFH_VALIDATE", "YFH_ALWAYS_WALK", "YFH_NO_READBACK", "YFH_THREADS", "YFH_NO_PATCH", "YFH_ECS_INPUTS"):
             if k not in env:
                 e.pop(k, None)
         r = subprocess.run([binary, scene, os.path.join(d, "out.bin")], env=e, capture_output=True, text=True, timeout=1200)
         times = [line.split(": ")[1].split(" ms")[0] for line in r.stderr.splitlines() if line.startswith("frame ")]
         print(f"{label:90s} n={n} L={levels}  ms per frame: " + "  ".join(times), flush=True)
         for line in r.stderr.splitlines():
-            if line.startswith("stages ") and env in ({}, {"YFH_THREADS": "1"}):
+            if line.startswith("stages ") and env in ({}, {"YFH_ECS_INPUTS": "1"}) and line.split()[1] in ("0:", "2:", "4:", "6:", "8:"):
                 print("    " + line, flush=True)

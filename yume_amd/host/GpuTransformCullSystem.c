@@ -15,6 +15,9 @@
  *      frame recomputed or found dirty come back (yh_download_changed_aos68) — a frame in which nothing moved
  *      exchanges no rows at all.  The frame applies the three-branch rule (TransformSyncSystem.zig:53-74) level by
  *      level and then clears every dirty flag (PostTransformSystem.zig:27-37), the root's included.
+ *   4. structural changes (observers, not polling): while no id was added to or removed from a table that holds one of
+ *      the components, steps 1-2 are skipped altogether; a few tables that gained or lost rows are patched (patch():
+ *      their rows move to spare slots of their level, no walk, no rebuild); anything else walks and rebuilds.
  *
  * Difference from the CPU systems worth knowing: the reference visits tables in flecs' storage order and
  * is parent-first only when entities were created parent-first; a child table stored before its parent's table reads
