@@ -1567,8 +1567,20 @@ int GpuTransformCullSystem_setBounds(GpuTransformCullSystem* s, ecs_entity_t ent
         s->bounds_n += 1;
     }
     memcpy(b->mm, min_max, sizeof b->mm);
-    s->bounds_stale = 1;
-    return YH_OK;
+    if (s->bounds_stale || !s->scene) {
+        s->bounds_stale = 1;
+        return YH_OK;
+    }
+    /* a scene is up: one entity's bounds do not make every entity's go up again */
+    uint32_t slot;
+    if (!slot_lookup(s, entity, &slot)) return YH_OK; /* no slot yet: whatever gives it one (patch, rebuild) reads the entry */
+    if (s->scene_bounds_kind == YH_BOUNDS_MESH_TABLE) {
+        s->bounds_stale = 1; /* (an entry of its own in the mesh table: the full upload hands those out) */
+        return YH_OK;
+    }
+    const float* mn[3] = {&b->mm[0], &b->mm[1], &b->mm[2]};
+    const float* mx[3] = {&b->mm[3], &b->mm[4], &b->mm[5]};
+    return yh_upload_aabb(s->scene, mn, mx, slot, 1);
 }
 
 int GpuTransformCullSystem_setFrusta(GpuTransformCullSystem* s, const float* planes, uint32_t n_frusta) {
