@@ -28,6 +28,7 @@
 #include <pthread.h>
 #include <sched.h>
 #include <stdatomic.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -188,6 +189,17 @@ static void map_put(Map* m, ecs_entity_t k, uint32_t v) {
     m->e[i].value = v;
 }
 
+/* keys[i] -> i for every non-zero key.  A map of a million entities is far larger than the caches and every insert a
+ * miss: the home slot of the key sixteen ahead is prefetched while this one is placed (43 + 36 ms of the 1M-entity
+ * rebuild were these two loops). */
+static void map_fill(Map* m, const ecs_entity_t* keys, uint64_t n) {
+    const uint64_t mask = m->cap - 1;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (i + 16 < n) __builtin_prefetch(&m->e[hash64(keys[i + 16]) & mask], 1);
+        if (keys[i]) map_put(m, keys[i], (uint32_t)i);
+    }
+}
+
 static int map_get(const Map* m, ecs_entity_t k, uint32_t* v) {
     uint64_t i = hash64(k) & (m->cap - 1);
     while (m->e[i].key) {
@@ -270,14 +282,17 @@ static int walk(GpuTransformCullSystem* s, ecs_iter_t* it) {
         }
         if ((rc = reserve_rows(s, s->n + (uint64_t)it->count)) != YH_OK) continue;
         Batch* b = &s->batches[s->n_batches++];
-        b->world_col = ecs_field_w_size(it, ROW, 0);
-        b->local_col = ecs_field_w_size(it, ROW, 1);
-        b->up_row = ecs_field_w_size(it, ROW, 2);
         b->table = it->table;
         b->col_w = it->table ? ecs_table_get_column_index(it->real_world, it->table, s->world_id) : -1;
         b->col_l = it->table ? ecs_table_get_column_index(it->real_world, it->table, s->local_id) : -1;
-        if (!it->table || it->offset != 0 || it->count != ecs_table_count(it->table) || b->col_w < 0 || b->col_l < 0)
+        if (!it->table || it->offset != 0 || it->count != ecs_table_count(it->table) || b->col_w < 0 || b->col_l < 0) {
             s->walk_is_whole_tables = 0;
+            b->world_col = ecs_field_w_size(it, ROW, 0);
+            b->local_col = ecs_field_w_size(it, ROW, 1);
+        } else { /* a whole table: its columns are fetched when a row of them is first needed (batch_cols) */
+            b->world_col = b->local_col = NULL;
+        }
+        b->up_row = NULL;
         b->src = ecs_field_src(it, 2);
         b->count = (uint32_t)it->count;
         b->walk_begin = (uint32_t)s->n;
@@ -322,7 +337,20 @@ static int by_key(const void* a, const void* b) {
     return x->batch < y->batch ? -1 : (x->batch > y->batch); /* stable: walk order among equals */
 }
 
+static double now_ms(void);
+/* YUME_GPU_SYSTEM_TRACE=1: the rebuild's steps with their wall time on stderr */
+#define TRACE_STEP(what)                                                                  \
+    do {                                                                                  \
+        if (trace) {                                                                      \
+            const double t_now = now_ms();                                                \
+            fprintf(stderr, "GpuTransformCullSystem rebuild: %-28s %8.3f ms\n", what, t_now - t_step); \
+            t_step = t_now;                                                               \
+        }                                                                                 \
+    } while (0)
+
 static int rebuild(GpuTransformCullSystem* s) {
+    const int trace = getenv("YUME_GPU_SYSTEM_TRACE") != NULL;
+    double t_step = trace ? now_ms() : 0.0;
     const uint64_t n = s->n;
     const uint32_t nb = s->n_batches;
     int rc = YH_OK;
@@ -342,9 +370,10 @@ static int rebuild(GpuTransformCullSystem* s) {
         goto done;
     }
     /* entity -> walk row; the batch of a row is found by binary search over walk_begin */
-    for (uint64_t r = 0; r < n; ++r) map_put(&batch_of, s->walk_entities[r], (uint32_t)r);
+    map_fill(&batch_of, s->walk_entities, n);
     for (uint32_t b = 0; b < nb; ++b) {
         uint32_t row;
+        if (b + 16 < nb) __builtin_prefetch(&batch_of.e[hash64(s->batches[b + 16].src) & (batch_of.cap - 1)]);
         if (map_get(&batch_of, s->batches[b].src, &row)) {
             uint32_t lo = 0, hi = nb - 1;
             while (lo < hi) {
@@ -359,6 +388,7 @@ static int rebuild(GpuTransformCullSystem* s) {
             parent_row[b] = YH_NO_PARENT;
         }
     }
+    TRACE_STEP("entity map, parents of tables");
     /* levels, memoised along parent chains (ChildOf is acyclic) */
     uint32_t n_levels = 0;
     for (uint32_t b = 0; b < nb; ++b) {
@@ -377,6 +407,7 @@ static int rebuild(GpuTransformCullSystem* s) {
         rc = YH_ERR_UNSUPPORTED;
         goto done;
     }
+    TRACE_STEP("levels");
     /* level by level: order the level's batches by the slot of their parent, hand out slots; with patching on every
      * level's range ends in spare slots for the tables that change later (patch()) */
     const int spare_slots = s->patching && s->incremental;
@@ -416,6 +447,7 @@ static int rebuild(GpuTransformCullSystem* s) {
     level_offsets[n_levels] = slot;
     const uint64_t N = slot; /* slots of the device scene */
     memcpy(s->level_begin, level_offsets, sizeof(uint32_t) * (n_levels + 1));
+    TRACE_STEP("sort by parent slot, slots");
 
     const uint32_t want_bounds = s->mesh_id ? YH_BOUNDS_MESH_TABLE : YH_BOUNDS_PER_ENTITY;
     if (!s->scene || s->scene_entities != N || s->scene_levels != n_levels || s->scene_bounds_kind != want_bounds) {
@@ -460,6 +492,7 @@ static int rebuild(GpuTransformCullSystem* s) {
             memset(s->stage_l + first, 0, bytes);
         }
     s->n_slots = N;
+    TRACE_STEP("device scene, staging columns");
     if ((rc = yh_upload_hierarchy(s->scene, parent_index, level_offsets)) != YH_OK) goto done;
     if (spare_slots) { /* (a scene that is reused may carry the dead slots of earlier patches) */
         if ((rc = yh_scene_set_alive_range(s->scene, 0, N, 1)) != YH_OK) goto done;
@@ -469,6 +502,7 @@ static int rebuild(GpuTransformCullSystem* s) {
     }
     memset(s->entity_of_slot, 0, (size_t)N * sizeof(ecs_entity_t)); /* 0: the slot holds no entity */
     memset(s->batch_of, 0xFF, (size_t)N * sizeof(uint32_t));
+    TRACE_STEP("hierarchy up, alive slots");
     for (uint32_t b = 0; b < nb; ++b)
         memcpy(s->entity_of_slot + s->batches[b].slot_begin, s->walk_entities + s->batches[b].walk_begin,
                sizeof(ecs_entity_t) * s->batches[b].count);
@@ -482,9 +516,9 @@ static int rebuild(GpuTransformCullSystem* s) {
         rc = YH_ERR_OOM;
         goto done;
     }
-    for (uint64_t e = 0; e < N; ++e)
-        if (s->entity_of_slot[e]) map_put(&s->slot_of, s->entity_of_slot[e], (uint32_t)e);
+    map_fill(&s->slot_of, s->entity_of_slot, N);
     s->slot_entries = n;
+    TRACE_STEP("entity -> slot map");
     for (int k = 0; k < 2; ++k) {
         free(s->stamp[k]);
         s->stamp[k] = (uint32_t*)calloc((size_t)(N ? N : 1), sizeof(uint32_t));
@@ -501,6 +535,7 @@ static int rebuild(GpuTransformCullSystem* s) {
         goto done;
     }
     if ((rc = yh_scene_track_changes(s->scene, s->incremental)) != YH_OK) goto done;
+    TRACE_STEP("stamps, slot list, tracking");
 
     /* remember this walk */
     {
@@ -539,6 +574,7 @@ static int rebuild(GpuTransformCullSystem* s) {
         s->walk_cache_valid = 1;
     }
     s->rebuilds += 1;
+    TRACE_STEP("walk remembered");
 done:
     free(batch_of.e);
     free(parent_batch);
@@ -660,17 +696,46 @@ done:
     return rc;
 }
 
+typedef struct BoundsJob {
+    const GpuTransformCullSystem* s;
+    float* planes;
+    uint64_t e0, e1;
+} BoundsJob;
+static void* bounds_thread(void* arg) {
+    const BoundsJob* j = (const BoundsJob*)arg;
+    const GpuTransformCullSystem* s = j->s;
+    const uint64_t n = s->n_slots;
+    for (uint64_t e = j->e0; e < j->e1; ++e) {
+        const BoundsEntry* b = s->entity_of_slot[e] ? bounds_find(s, s->entity_of_slot[e]) : NULL;
+        if (b)
+            for (int k = 0; k < 6; ++k) j->planes[(size_t)k * n + e] = b->mm[k];
+    }
+    return NULL;
+}
+
 static int upload_bounds(GpuTransformCullSystem* s) {
     if (s->scene_bounds_kind == YH_BOUNDS_MESH_TABLE) return upload_bounds_from_meshes(s);
     const uint64_t n = s->n_slots;
     float* planes = (float*)calloc((size_t)n * 6, sizeof(float)); /* no bounds = empty box at the origin */
     if (!planes) return YH_ERR_OOM;
-    if (s->bounds_n)
-        for (uint64_t e = 0; e < n; ++e) {
-            const BoundsEntry* b = s->entity_of_slot[e] ? bounds_find(s, s->entity_of_slot[e]) : NULL;
-            if (b)
-                for (int k = 0; k < 6; ++k) planes[(size_t)k * n + e] = b->mm[k];
+    if (s->bounds_n) { /* one hash lookup per slot, every one a cache miss: helpers share them (read-only) */
+        uint64_t parts = n / ROWS_PER_THREAD_MIN > (uint64_t)s->threads ? (uint64_t)s->threads : n / ROWS_PER_THREAD_MIN;
+        if (parts < 1) parts = 1;
+        pthread_t th[MAX_THREADS];
+        BoundsJob job[MAX_THREADS];
+        int started[MAX_THREADS];
+        for (uint64_t p = 0; p < parts; ++p) {
+            job[p].s = s;
+            job[p].planes = planes;
+            job[p].e0 = n * p / parts;
+            job[p].e1 = n * (p + 1) / parts;
+            started[p] = p > 0 && pthread_create(&th[p], NULL, bounds_thread, &job[p]) == 0;
         }
+        for (uint64_t p = 0; p < parts; ++p)
+            if (!started[p]) bounds_thread(&job[p]);
+        for (uint64_t p = 1; p < parts; ++p)
+            if (started[p]) pthread_join(th[p], NULL);
+    }
     const float* mn[3] = {planes, planes + n, planes + 2 * n};
     const float* mx[3] = {planes + 3 * n, planes + 4 * n, planes + 5 * n};
     const int rc = yh_upload_aabb(s->scene, mn, mx, 0, n);
@@ -995,6 +1060,55 @@ static uint64_t gather_dirty(GpuTransformCullSystem* s, int k, uint8_t* stage) {
         }
     }
     return m;
+}
+
+/* ---- whole columns between the tables and the staging columns, shared by helper threads ------------------------ */
+typedef struct ColumnsJob {
+    GpuTransformCullSystem* s;
+    uint32_t b0, b1; /* batches */
+    int to_stage;    /* 1: tables -> staging columns, 0: back */
+} ColumnsJob;
+static void* columns_thread(void* arg) {
+    const ColumnsJob* j = (const ColumnsJob*)arg;
+    GpuTransformCullSystem* s = j->s;
+    for (uint32_t i = j->b0; i < j->b1; ++i) {
+        if (!s->batches[i].count) continue; /* (a batch whose rows moved away: patch()) */
+        const Batch* b = batch_cols(&s->batches[i]); /* each batch is one thread's: its column pointers are filled in here */
+        uint8_t *sw = s->stage_w + (size_t)b->slot_begin * ROW, *sl = s->stage_l + (size_t)b->slot_begin * ROW;
+        const size_t bytes = (size_t)b->count * ROW;
+        if (j->to_stage) {
+            memcpy(sw, b->world_col, bytes);
+            memcpy(sl, b->local_col, bytes);
+        } else {
+            memcpy(b->world_col, sw, bytes);
+            memcpy(b->local_col, sl, bytes);
+        }
+    }
+    return NULL;
+}
+/* 136 MB in 300k pieces at 1M entities: 57-78 ms on one thread, most of it cache misses */
+static void copy_columns(GpuTransformCullSystem* s, int to_stage) {
+    uint32_t parts = s->n / ROWS_PER_THREAD_MIN > (uint64_t)s->threads ? (uint32_t)s->threads : (uint32_t)(s->n / ROWS_PER_THREAD_MIN);
+    if (parts > s->n_batches) parts = s->n_batches;
+    if (parts < 2) {
+        ColumnsJob all = {s, 0, s->n_batches, to_stage};
+        columns_thread(&all);
+        return;
+    }
+    pthread_t th[MAX_THREADS];
+    ColumnsJob job[MAX_THREADS];
+    int started[MAX_THREADS];
+    for (uint32_t p = 0; p < parts; ++p) {
+        job[p].s = s;
+        job[p].b0 = (uint32_t)((uint64_t)s->n_batches * p / parts);
+        job[p].b1 = (uint32_t)((uint64_t)s->n_batches * (p + 1) / parts);
+        job[p].to_stage = to_stage;
+        started[p] = p > 0 && pthread_create(&th[p], NULL, columns_thread, &job[p]) == 0;
+    }
+    for (uint32_t p = 0; p < parts; ++p)
+        if (!started[p]) columns_thread(&job[p]); /* part 0, and any part whose thread did not start */
+    for (uint32_t p = 1; p < parts; ++p)
+        if (started[p]) pthread_join(th[p], NULL);
 }
 
 /* ---- small structural changes without a rebuild ----------------------------------------------------------- */
@@ -1392,11 +1506,7 @@ static void run(ecs_iter_t* it) {
     const double t_inputs = now_ms();
     if (!s->incremental || rebuilt) {
         /* whole columns up; in plain mode whole columns down again */
-        for (uint32_t i = 0; i < s->n_batches; ++i) {
-            const Batch* b = batch_cols(&s->batches[i]);
-            memcpy(s->stage_w + (size_t)b->slot_begin * ROW, b->world_col, (size_t)b->count * ROW);
-            memcpy(s->stage_l + (size_t)b->slot_begin * ROW, b->local_col, (size_t)b->count * ROW);
-        }
+        copy_columns(s, 1);
         if ((rc = yh_upload_world_aos68(s->scene, s->stage_w, 0, s->n_slots)) != YH_OK ||
             (rc = yh_upload_local_aos68(s->scene, s->stage_l, 0, s->n_slots)) != YH_OK) {
             s->status = rc;
@@ -1446,11 +1556,7 @@ static void run(ecs_iter_t* it) {
             s->status = rc;
             return;
         }
-        for (uint32_t i = 0; i < s->n_batches; ++i) {
-            const Batch* b = batch_cols(&s->batches[i]);
-            memcpy(b->world_col, s->stage_w + (size_t)b->slot_begin * ROW, (size_t)b->count * ROW);
-            memcpy(b->local_col, s->stage_l + (size_t)b->slot_begin * ROW, (size_t)b->count * ROW);
-        }
+        copy_columns(s, 0);
         s->last_down_rows = 2 * s->n_slots;
         s->host_stale = 0;
     } else {
