@@ -37,7 +37,8 @@
  *            (query iterations done / frames that reused the last one).  GPU build, env YFH_PLAIN=1: whole columns both
  *            ways every frame instead of the incremental mode; YFH_ALWAYS_WALK=1: iterate the query every frame;
  *            YFH_NO_READBACK=1: rows stay on the device (setReadback(0)) until the last frame, which brings whole columns back;
- *            YFH_VALIDATE=1: do not trust the structural-change observers, compare every cached table every frame.
+ *            YFH_VALIDATE=1: do not trust the structural-change observers, compare every cached table every frame;
+ *            YFH_NO_PATCH=1: setPatching(0); YFH_READBACK_OFF_FROM=k: setReadback(0) from frame k to the last but one.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -348,6 +349,11 @@ int main(int argc, char** argv) {
         g_batches = g_rows = 0;
 #ifdef USE_GPU_SYSTEM
         if (no_readback && f + 1 == n_frames) GpuTransformCullSystem_setReadback(gpu, 1); /* the last frame catches flecs up */
+        if (getenv("YFH_READBACK_OFF_FROM")) { /* readback on, then off from that frame, on again for the last one */
+            const uint32_t from = (uint32_t)atoi(getenv("YFH_READBACK_OFF_FROM"));
+            if (f == from) GpuTransformCullSystem_setReadback(gpu, 0);
+            if (f + 1 == n_frames) GpuTransformCullSystem_setReadback(gpu, 1);
+        }
 #endif
         struct timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);

@@ -444,3 +444,49 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
         for f in range(cull_planes.shape[0]):
             assert np.array_equal(np.sort(vis[f]), here[np.flatnonzero(exp_vis[f])]), f"frame {fi} frustum {f}: visible set {stats}"
     assert patches >= 3 and rebuilds >= 2, f"the script was meant to exercise both paths: {patches} patches, {rebuilds} rebuilds"
+
+
+def test_readback_switched_off_and_on_again_after_patches(oracle, tmp_path):
+    """Patches leave dead batches and dead slots behind; whole columns must still travel correctly when readback is
+    switched off afterwards (no patching then: structural changes rebuild) and on again."""
+    n, levels = 30_000, 6
+    rng = np.random.default_rng(5)
+    lo = oracle.synth_level_offsets(n, levels)
+    par = oracle.synth_parents(lo)
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo[1])))
+    bounds = oracle.synth_aabb(n)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+
+    def rnd_m(scale=5.0):
+        return oracle.compose(rng.uniform(-scale, scale, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+
+    last = np.arange(int(lo[-2]), n)
+    doomed = rng.choice(last, 30, replace=False)
+    movers = np.setdiff1d(last, doomed)[:12]
+    new_par = rng.integers(int(lo[-3]), int(lo[-2]), movers.size)
+    frames = [[], [(int(e), 2, np.zeros(16, np.float32)) for e in doomed[:15]],                      # patched
+              [(int(e), 3, reparent_arg(int(p))) for e, p in zip(movers, new_par)],                   # patched
+              [(int(e), 0, rnd_m()) for e in np.unique(rng.integers(0, int(lo[-2]), 200))],
+              [(int(e), 1, rnd_m(50.0)) for e in np.unique(rng.integers(0, int(lo[-2]), 100))],       # readback off from here
+              [(int(e), 2, np.zeros(16, np.float32)) for e in doomed[15:]],                           # structural, stale host: rebuild
+              [(-1, 1, oracle.compose([1, 2, 3], [0, 0.7071068, 0, 0.7071068], [2, 2, 2]))],
+              []]                                                                                    # readback on: columns come home
+    scene, out_c, out_g = tmp_path / "scene.bin", tmp_path / "cpu.bin", tmp_path / "gpu.bin"
+    write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
+    subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
+    env["YFH_READBACK_OFF_FROM"] = "4"
+    subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
+    cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
+    gpu = read_out(out_g, n, len(frames), 1, oracle.T68, gpu=True)
+    assert gpu[2][4][-1][4] == 2, "frames 1 and 2 were meant to be patched"
+    for fi, ((cw, cl, _, rows, _), (gw, gl, _reb, g_rows, vis)) in enumerate(zip(cpu, gpu)):
+        assert g_rows == rows
+        here = np.flatnonzero(cw["m"].any(axis=1) | cl["m"].any(axis=1))
+        exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[here]), np.ascontiguousarray(bounds[here]), planes)
+        assert np.array_equal(np.sort(vis[0]), here[np.flatnonzero(exp_vis[0])]), f"frame {fi}: visible set (device state)"
+        if fi < 4 or fi + 1 == len(frames):  # while readback is on, flecs' columns are the CPU systems'
+            with np.errstate(all="ignore"):
+                assert np.array_equal(gw["m"], cw["m"], equal_nan=True), f"frame {fi}: world matrices"
+                assert np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi}: local matrices"
+            assert np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"]), f"frame {fi}: dirty bytes"
