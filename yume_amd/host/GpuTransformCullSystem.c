@@ -920,9 +920,14 @@ static void scatter_work(ScatterStream* t) {
         const uint64_t i0 = atomic_fetch_add_explicit(&t->cursor, SCATTER_GRAIN, memory_order_relaxed);
         if (i0 >= t->total) return;
         const uint64_t i1 = i0 + SCATTER_GRAIN < t->total ? i0 + SCATTER_GRAIN : t->total;
-        while (atomic_load_explicit(&t->ready, memory_order_acquire) < i1) {
+        for (uint32_t spins = 0; atomic_load_explicit(&t->ready, memory_order_acquire) < i1; ++spins) {
             if (atomic_load_explicit(&t->stop, memory_order_relaxed)) return;
-            sched_yield();
+            if (spins < 32) {
+                sched_yield();
+            } else { /* a piece takes ~100 us to cross PCIe: sixteen spinning helpers only burn the process' CPU share */
+                const struct timespec nap = {0, 5000};
+                nanosleep(&nap, NULL);
+            }
         }
         scatter_range(t->s, t->k, t->slots, t->stage, i0, i1);
     }
