@@ -443,7 +443,7 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
         exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[here]), np.ascontiguousarray(cull_bounds[here]), cull_planes)
         for f in range(cull_planes.shape[0]):
             assert np.array_equal(np.sort(vis[f]), here[np.flatnonzero(exp_vis[f])]), f"frame {fi} frustum {f}: visible set {stats}"
-    assert patches >= 3 and rebuilds >= 2, f"the script was meant to exercise both paths: {patches} patches, {rebuilds} rebuilds"
+    assert patches >= 3 and rebuilds >= 1, f"the script was meant to exercise the patch path: {patches} patches, {rebuilds} rebuilds"
 
 
 def test_readback_switched_off_and_on_again_after_patches(oracle, tmp_path):
@@ -490,3 +490,152 @@ def test_readback_switched_off_and_on_again_after_patches(oracle, tmp_path):
                 assert np.array_equal(gw["m"], cw["m"], equal_nan=True), f"frame {fi}: world matrices"
                 assert np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi}: local matrices"
             assert np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"]), f"frame {fi}: dirty bytes"
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("YH_STRUCT_SEEDS", "3"))))
+def test_subtrees_moved_to_other_depths_patched_equals_rebuilt(oracle, tmp_path, seed):
+    """Whole subtrees dragged under parents of any depth, children created under parents created in the same frame,
+    leaves deleted, matrices edited: the patched system (rows of every batch below a moved row follow it to another
+    level's spare slots) against the same system rebuilding on every structural change (setPatching(0)), row for row and
+    visible set for visible set.  (The CPU systems are no yardstick here: moved subtrees leave flecs' table order
+    parent-last, where the reference lags a frame - SURVEY F5; both GPU runs are parent-first.)"""
+    rng = np.random.default_rng(5000 + seed)
+    n0, levels, extra = 12_000, 7, 800
+    n = n0 + extra
+    lo0 = oracle.synth_level_offsets(n0, levels - 2)  # two levels of headroom for subtrees that move down
+    par0 = oracle.synth_parents(lo0)
+    lo = np.concatenate([lo0, [n0, n0, n]]).astype(np.uint32)
+    parent = np.concatenate([par0, np.full(extra, 0xFFFFFFFE, np.uint32)])
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo0[1])))
+    bounds = oracle.synth_aabb(n)
+    planes = np.concatenate([oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()[:1]])
+
+    def rnd_m(scale=5.0):
+        return oracle.compose(rng.uniform(-scale, scale, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+
+    cur_parent = {e: (int(par0[e]) if par0[e] != 0xFFFFFFFF else -1) for e in range(n0)}
+    children = {}
+    for e, p in cur_parent.items():
+        children.setdefault(p, set()).add(e)
+    depth = {e: int(np.searchsorted(lo0, e, side="right") - 1) for e in range(n0)}
+    alive = set(range(n0))
+    next_new = n0
+
+    def subtree(e):
+        out, stack = [], [e]
+        while stack:
+            x = stack.pop()
+            out.append(x)
+            stack.extend(children.get(x, ()))
+        return out
+
+    # the scene's deepest level sets how many levels the device scene has until a rebuild: the first frames push one
+    # chain down to the last level so that later moves have room on every level
+    frames = [[]]
+    deepest = max(depth, key=depth.get)
+    chain = []
+    for _ in range(levels - 1 - depth[deepest]):
+        e = next_new
+        next_new += 1
+        chain.append((e, 6, reparent_arg(deepest)))
+        cur_parent[e], depth[e] = deepest, depth[deepest] + 1
+        children.setdefault(deepest, set()).add(e)
+        alive.add(e)
+        deepest = e
+        frames.append([chain[-1]])
+    for fi in range(22):
+        edits = []
+        pool = np.array(sorted(alive))
+        what = rng.integers(0, 5)
+        if what == 0:  # a subtree under a parent of ANY depth (that keeps it inside the scene's levels)
+            for _try in range(40):
+                e, p = int(rng.choice(pool)), int(rng.choice(pool))
+                sub = subtree(e)
+                if depth[e] == 0 or not children.get(e) or p in sub or len(sub) > 400:
+                    continue
+                if depth[p] + 1 + max(depth[x] for x in sub) - depth[e] >= levels:
+                    continue
+                edits.append((e, 3, reparent_arg(p)))
+                children[cur_parent[e]].discard(e)
+                shift = depth[p] + 1 - depth[e]
+                for x in sub:
+                    depth[x] += shift
+                cur_parent[e] = p
+                children.setdefault(p, set()).add(e)
+                break
+        elif what == 1 and next_new + 30 <= n:  # a parent and its children created in ONE frame
+            p = int(rng.choice(pool))
+            if depth[p] + 2 < levels:
+                e = next_new
+                next_new += 1
+                edits.append((e, 6, reparent_arg(p)))
+                cur_parent[e], depth[e] = p, depth[p] + 1
+                children.setdefault(p, set()).add(e)
+                alive.add(e)
+                for _ in range(int(rng.integers(1, 6))):
+                    c = next_new
+                    next_new += 1
+                    edits.append((c, 6, reparent_arg(e)))
+                    cur_parent[c], depth[c] = e, depth[e] + 1
+                    children.setdefault(e, set()).add(c)
+                    alive.add(c)
+        elif what == 2:  # leaves deleted
+            for e in dict.fromkeys(int(x) for x in rng.choice(pool, 40)):
+                if children.get(e) or e not in alive:
+                    continue
+                edits.append((e, 2, np.zeros(16, np.float32)))
+                children[cur_parent[e]].discard(e)
+                alive.discard(e)
+        elif what == 3:  # leaves under other parents of any depth
+            for e in dict.fromkeys(int(x) for x in rng.choice(pool, 30)):
+                p = int(rng.choice(pool))
+                if children.get(e) or p == e or depth[p] + 1 >= levels or depth[e] == 0:
+                    continue
+                edits.append((e, 3, reparent_arg(p)))
+                children[cur_parent[e]].discard(e)
+                cur_parent[e], depth[e] = p, depth[p] + 1
+                children.setdefault(p, set()).add(e)
+        pool = np.array(sorted(alive))
+        for e in np.unique(rng.choice(pool, int(rng.integers(0, 80)))):
+            edits.append((int(e), int(rng.integers(0, 2)), rnd_m()))
+        frames.append(edits)
+    frames.append([])
+
+    scene = tmp_path / "scene.bin"
+    write_scene(scene, lo, parent, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
+    outs = {}
+    for mode in ("patched", "rebuilt"):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
+        if mode == "rebuilt":
+            env["YFH_NO_PATCH"] = "1"
+        out = tmp_path / f"{mode}.bin"
+        subprocess.check_call([GPU, str(scene), str(out)], timeout=300, env=env)
+        outs[mode] = read_out(out, n, len(frames), planes.shape[0], oracle.T68, gpu=True)
+    for fi, ((pw, pl, _pr, p_rows, pvis), (rw, rl, _rr, r_rows, rvis)) in enumerate(zip(outs["patched"], outs["rebuilt"])):
+        stats = f"patched {pvis[-1]}, rebuilt {rvis[-1]}, edits {[(e, k) for e, k, _ in frames[fi]][:6]}"
+        with np.errstate(all="ignore"):
+            assert np.array_equal(pw["m"], rw["m"], equal_nan=True), f"frame {fi}: world matrices {stats}"
+            assert np.array_equal(pl["m"], rl["m"], equal_nan=True), f"frame {fi}: local matrices {stats}"
+        assert np.array_equal(pw["dirty"], rw["dirty"]) and np.array_equal(pl["dirty"], rl["dirty"]), f"frame {fi}: dirty bytes {stats}"
+        assert p_rows == r_rows == len(alive_at(frames, fi, n0, parent)), f"frame {fi}: rows {stats}"
+        for f in range(planes.shape[0]):
+            assert np.array_equal(np.sort(pvis[f]), np.sort(rvis[f])), f"frame {fi} frustum {f}: visible set {stats}"
+    assert outs["patched"][-1][4][-1][4] >= 8, f"most structural frames were meant to be patched: {outs['patched'][-1][4][-1]}"
+
+
+def alive_at(frames, upto, n0, parent):
+    """Entities that exist after frame `upto` of a script (creations, deletions with their subtrees)."""
+    par = {e: int(parent[e]) for e in range(n0)}
+    for fi in range(upto + 1):
+        for e, kind, m in frames[fi]:
+            if kind == 6 or kind == 3:
+                par[e] = int(np.asarray(m, np.float32).view(np.uint32)[0])
+            elif kind == 2:
+                doomed, grew = {e}, True
+                while grew:
+                    more = {x for x, p in par.items() if p in doomed and x not in doomed}
+                    grew = bool(more)
+                    doomed |= more
+                for x in doomed:
+                    par.pop(x, None)
+    return par

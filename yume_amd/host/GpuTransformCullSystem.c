@@ -49,6 +49,7 @@ typedef struct Batch {
     uint32_t count;
     uint32_t walk_begin; /* first row in walk order */
     uint32_t slot_begin; /* first row in slot order */
+    uint32_t parent_slot; /* slot of src (YH_NO_PARENT at level 0): every row of the batch has this parent */
     int32_t level;
 } Batch;
 
@@ -156,7 +157,7 @@ struct GpuTransformCullSystem {
     uint32_t n_touched, cap_touched;
     int need_full;                /* an event patch() cannot follow: a table deleted, too many tables touched */
     int walk_cache_valid;         /* cached_* describe the batches (false after a patch: the next walk rebuilds) */
-    uint32_t* cached_slot;        /* per batch: slot_begin as the last rebuild assigned it */
+    uint32_t* cached_slot;        /* per batch: slot_begin and parent_slot as the last rebuild assigned them */
     uint64_t slot_entries;        /* entries put into slot_of (stale ones stay until the next rebuild) */
     uint64_t patches, last_patch_tables;
 
@@ -433,6 +434,7 @@ static int rebuild(GpuTransformCullSystem* s) {
             Batch* b = &s->batches[s->order[i]];
             b->slot_begin = slot;
             const uint32_t p = lvl == 0 ? YH_NO_PARENT : key[s->order[i]];
+            b->parent_slot = p;
             for (uint32_t r = 0; r < b->count; ++r) parent_index[slot + r] = p;
             slot += b->count;
         }
@@ -545,7 +547,7 @@ static int rebuild(GpuTransformCullSystem* s) {
         int32_t* cl = (int32_t*)realloc(s->cached_levels, (size_t)(nb ? nb : 1) * sizeof(int32_t));
         ecs_table_t** ct = (ecs_table_t**)realloc(s->cached_tables, (size_t)(nb ? nb : 1) * sizeof(ecs_table_t*));
         int32_t* ccol = (int32_t*)realloc(s->cached_cols, (size_t)(nb ? nb : 1) * 2 * sizeof(int32_t));
-        uint32_t* cslot = (uint32_t*)realloc(s->cached_slot, (size_t)(nb ? nb : 1) * sizeof(uint32_t));
+        uint32_t* cslot = (uint32_t*)realloc(s->cached_slot, (size_t)(nb ? nb : 1) * 2 * sizeof(uint32_t));
         if (cslot) s->cached_slot = cslot;
         if (ct) s->cached_tables = ct;
         if (ccol) s->cached_cols = ccol;
@@ -567,7 +569,8 @@ static int rebuild(GpuTransformCullSystem* s) {
             ct[b] = s->batches[b].table;
             ccol[2 * b] = s->batches[b].col_w;
             ccol[2 * b + 1] = s->batches[b].col_l;
-            cslot[b] = s->batches[b].slot_begin;
+            cslot[2 * b] = s->batches[b].slot_begin;
+            cslot[2 * b + 1] = s->batches[b].parent_slot;
         }
         s->cached_n = n;
         s->cached_batches = nb;
@@ -749,7 +752,8 @@ static void restore_slots(GpuTransformCullSystem* s) {
     for (uint32_t i = 0; i < s->n_batches; ++i) {
         Batch* b = &s->batches[i];
         b->level = s->cached_levels[i];
-        b->slot_begin = s->cached_slot[i]; /* (levels end in spare slots: not a running sum of the counts) */
+        b->slot_begin = s->cached_slot[2 * i]; /* (levels end in spare slots: not a running sum of the counts) */
+        b->parent_slot = s->cached_slot[2 * i + 1];
     }
 }
 
@@ -1162,7 +1166,9 @@ static int patch(GpuTransformCullSystem* s) {
     if (!nt) return YH_OK;
     PatchItem* items = (PatchItem*)calloc(nt, sizeof(PatchItem));
     uint32_t* old_of = (uint32_t*)malloc(sizeof(uint32_t) * nt); /* per listed table: its batch, or UINT32_MAX */
-    uint32_t* kids = NULL;  /* batches whose parent is a row that moves or leaves */
+    uint32_t* kids = NULL;  /* batches whose parent row moves inside its level */
+    uint8_t* reloc = NULL;
+    int32_t* new_level = NULL;
     uint32_t n_kids = 0, cap_kids = 0;
     Map moved = {0}; /* entity -> 1 + index of the item whose new content holds it, 0: it leaves */
     uint64_t rows_in = 0, rows_out = 0, need[YH_MAX_LEVELS];
@@ -1204,27 +1210,20 @@ static int patch(GpuTransformCullSystem* s) {
             it.level = b->level;
             if (it.count == b->count && memcmp(ents, s->entity_of_slot + b->slot_begin, sizeof(ecs_entity_t) * it.count) == 0)
                 continue; /* same rows in the same order (a component came and went) */
-            rows_out += b->count;
         } else {
             it.src = ecs_get_parent(s->world, ents[0]); /* ChildOf is part of the archetype: one parent per table */
             if (!it.src) continue;                      /* no parent: the Up term does not match this table */
-            uint32_t ps;
             if (!ecs_has_id(s->world, it.src, s->world_id)) goto not_a_patch; /* Up resolves further up, or not at all */
-            if (it.src == s->root) it.level = 0;
-            else if (slot_lookup(s, it.src, &ps)) it.level = level_of_slot(s, ps) + 1;
-            else goto not_a_patch; /* a parent this system does not hold (a second root, a parent created just now) */
-            if ((uint32_t)it.level >= s->n_levels) goto not_a_patch; /* a level deeper than the scene has */
+            it.level = -1; /* one below its parent's, found below (the parent may be a row of this very patch) */
         }
-        rows_in += it.count;
-        need[it.level] += it.count;
         items[ni++] = it;
     }
     if (!ni) goto done;
-    for (uint32_t l = 0; l < s->n_levels; ++l)
-        if ((uint64_t)s->level_fill[l] + need[l] > s->level_begin[l + 1]) goto not_a_patch; /* the level's spare slots are used up */
-    if ((s->slot_entries + rows_in) * 10 > s->slot_of.cap * 7) goto not_a_patch;          /* the entity -> slot map is filling up */
-    if (rows_in > s->n_slots / 4) goto not_a_patch;                                       /* most of a level moves: a rebuild is cheaper */
-    /* the rows that move or leave, and the batches that name one of them as their parent */
+    /* the rows that move or leave */
+    for (uint32_t i = 0; i < ni; ++i) {
+        rows_in += items[i].count;
+        if (items[i].old_batch != UINT32_MAX) rows_out += s->batches[items[i].old_batch].count;
+    }
     if (map_init(&moved, rows_in + rows_out + 8) != 0) {
         rc = YH_ERR_OOM;
         goto done;
@@ -1238,27 +1237,115 @@ static int patch(GpuTransformCullSystem* s) {
         const ecs_entity_t* ents = items[i].count ? ecs_table_entities(items[i].table) : NULL;
         for (uint32_t r = 0; r < items[i].count; ++r) map_put(&moved, ents[r], 1 + i);
     }
-    for (uint32_t b = 0; b < s->n_batches; ++b) {
-        const Batch* bt = &s->batches[b];
-        uint32_t where;
-        if (!bt->count || !bt->src || !map_get(&moved, bt->src, &where)) continue;
-        /* an entity that leaves while batches still name it as their parent, or a row that changes its level and so
-         * takes its whole subtree along: not leaf operations */
-        if (!where) goto not_a_patch;
-        uint32_t os;
-        if (slot_lookup(s, bt->src, &os) && level_of_slot(s, os) != items[where - 1].level) goto not_a_patch;
-        if (n_kids == cap_kids) {
-            const uint32_t cap = cap_kids ? cap_kids * 2 : 64;
-            uint32_t* g = (uint32_t*)realloc(kids, sizeof(uint32_t) * cap);
+    /* Levels.  A batch lives one level below its parent row.  A row that changed its level (a subtree re-parented to
+     * another depth) takes every batch below it along: those batches were not listed - their tables did not change -
+     * but their rows move to the spare slots of another level all the same.  reloc: 1 = listed batch (dies, its table's
+     * rows are placed anew), 2 = follows its parent to new_level.  Repeated until nothing changes (a subtree's height). */
+    reloc = (uint8_t*)calloc(s->n_batches ? s->n_batches : 1, 1);
+    new_level = (int32_t*)malloc(sizeof(int32_t) * (s->n_batches ? s->n_batches : 1));
+    if (!reloc || !new_level) {
+        rc = YH_ERR_OOM;
+        goto done;
+    }
+    for (uint32_t i = 0; i < ni; ++i)
+        if (items[i].old_batch != UINT32_MAX) reloc[items[i].old_batch] = 1;
+    for (uint32_t iter = 0;; ++iter) {
+        if (iter > YH_MAX_LEVELS + 2u) goto not_a_patch;
+        int changed = 0;
+        for (uint32_t i = 0; i < ni; ++i) { /* the listed tables: one level below their parent, wherever that is now */
+            PatchItem* it = &items[i];
+            int32_t lvl;
+            uint32_t where, ps;
+            if (it->src == s->root) lvl = 0;
+            else if (map_get(&moved, it->src, &where)) {
+                if (!where) goto not_a_patch; /* the parent left */
+                lvl = items[where - 1].level < 0 ? -1 : items[where - 1].level + 1;
+            } else if (slot_lookup(s, it->src, &ps)) {
+                const uint32_t pb = s->batch_of[ps];
+                lvl = (pb != UINT32_MAX && reloc[pb] == 2 ? new_level[pb] : level_of_slot(s, ps)) + 1;
+            } else goto not_a_patch; /* a parent this system does not hold (a second root) */
+            if (lvl != it->level) {
+                it->level = lvl;
+                changed = 1;
+            }
+        }
+        n_kids = 0;
+        for (uint32_t c = 0; c < s->n_batches; ++c) { /* every other batch: does its parent row move? */
+            const Batch* bt = &s->batches[c];
+            if (!bt->count || reloc[c] == 1 || bt->level == 0) continue;
+            const uint32_t pb = bt->parent_slot < s->n_slots ? s->batch_of[bt->parent_slot] : UINT32_MAX;
+            if (pb == UINT32_MAX) goto not_a_patch; /* (a live batch under a dead slot: not a state patch() leaves) */
+            if (!reloc[pb]) continue;
+            int32_t want;
+            if (reloc[pb] == 1) {
+                uint32_t where;
+                if (!map_get(&moved, bt->src, &where) || !where) goto not_a_patch; /* its parent leaves while it stays: not a leaf operation */
+                if (items[where - 1].level < 0) { /* (not known yet: next round) */
+                    changed = 1;
+                    continue;
+                }
+                want = items[where - 1].level + 1;
+            } else {
+                want = new_level[pb] + 1;
+            }
+            if (want == bt->level && reloc[c] == 0) { /* the parent row moves inside its level: a new parent slot is all */
+                if (n_kids == cap_kids) {
+                    const uint32_t cap = cap_kids ? cap_kids * 2 : 64;
+                    uint32_t* g = (uint32_t*)realloc(kids, sizeof(uint32_t) * cap);
+                    if (!g) {
+                        rc = YH_ERR_OOM;
+                        goto done;
+                    }
+                    kids = g;
+                    cap_kids = cap;
+                }
+                kids[n_kids++] = c;
+            } else if (reloc[c] != 2 || new_level[c] != want) {
+                reloc[c] = 2;
+                new_level[c] = want;
+                changed = 1;
+            }
+        }
+        if (!changed) break;
+    }
+    {   /* the batches that follow their parents become items of their own: same table, same rows, another level */
+        uint32_t n_follow = 0;
+        for (uint32_t c = 0; c < s->n_batches; ++c) n_follow += reloc[c] == 2;
+        if (n_follow) {
+            PatchItem* g = (PatchItem*)realloc(items, sizeof(PatchItem) * ((size_t)ni + n_follow));
             if (!g) {
                 rc = YH_ERR_OOM;
                 goto done;
             }
-            kids = g;
-            cap_kids = cap;
+            items = g;
+            for (uint32_t c = 0; c < s->n_batches; ++c) {
+                if (reloc[c] != 2) continue;
+                const Batch* bt = &s->batches[c];
+                PatchItem it;
+                memset(&it, 0, sizeof it);
+                it.table = bt->table;
+                it.old_batch = c;
+                it.new_batch = UINT32_MAX;
+                it.col_w = bt->col_w;
+                it.col_l = bt->col_l;
+                it.count = bt->count;
+                it.src = bt->src;
+                it.level = new_level[c];
+                if ((uint32_t)ecs_table_count(bt->table) != bt->count) goto not_a_patch; /* (its table changed unseen?) */
+                items[ni++] = it;
+                rows_in += bt->count;
+                rows_out += bt->count;
+            }
         }
-        kids[n_kids++] = b;
     }
+    for (uint32_t i = 0; i < ni; ++i) {
+        if (items[i].level < 0 || (uint32_t)items[i].level >= s->n_levels) goto not_a_patch; /* deeper than the scene's levels */
+        need[items[i].level] += items[i].count;
+    }
+    for (uint32_t l = 0; l < s->n_levels; ++l)
+        if ((uint64_t)s->level_fill[l] + need[l] > s->level_begin[l + 1]) goto not_a_patch; /* the level's spare slots are used up */
+    if ((s->slot_entries + rows_in) * 10 > s->slot_of.cap * 7) goto not_a_patch;          /* the entity -> slot map is filling up */
+    if (rows_in > s->n_slots / 4) goto not_a_patch;                                       /* most of a level moves: a rebuild is cheaper */
     /* room for the new batches */
     if (s->n_batches + ni > s->cap_batches) {
         uint32_t cap = s->cap_batches ? s->cap_batches : 256;
@@ -1350,22 +1437,24 @@ static int patch(GpuTransformCullSystem* s) {
     for (uint32_t i = 0; i < ni; ++i) { /* parent slots of the moved rows (their parent may have moved in this patch too) */
         const PatchItem* it = &items[i];
         if (!it->count) continue;
-        const Batch* b = &s->batches[it->new_batch];
+        Batch* b = &s->batches[it->new_batch];
         uint32_t ps = YH_NO_PARENT;
         if (b->level > 0 && !slot_lookup(s, b->src, &ps)) {
             rc = YH_ERR_STATE;
             goto done;
         }
+        b->parent_slot = ps;
         if ((rc = upload_parent_run(s, b->slot_begin, b->count, ps)) != YH_OK) goto done;
     }
-    for (uint32_t k = 0; k < n_kids; ++k) { /* and of the children of every moved row */
-        const Batch* c = &s->batches[kids[k]];
+    for (uint32_t k = 0; k < n_kids; ++k) { /* and of the batches whose parent row moved inside its level */
+        Batch* c = &s->batches[kids[k]];
         uint32_t ps;
-        if (!c->count) continue; /* (a child batch that was itself listed: moved above, with its parent's new slot) */
+        if (!c->count) continue;
         if (!slot_lookup(s, c->src, &ps)) {
             rc = YH_ERR_STATE;
             goto done;
         }
+        c->parent_slot = ps;
         if ((rc = upload_parent_run(s, c->slot_begin, c->count, ps)) != YH_OK) goto done;
     }
     s->patches += 1;
@@ -1374,12 +1463,16 @@ done:
     free(items);
     free(old_of);
     free(kids);
+    free(reloc);
+    free(new_level);
     free(moved.e);
     return rc;
 not_a_patch:
     free(items);
     free(old_of);
     free(kids);
+    free(reloc);
+    free(new_level);
     free(moved.e);
     return 1;
 }
