@@ -639,3 +639,35 @@ def alive_at(frames, upto, n0, parent):
                 for x in doomed:
                     par.pop(x, None)
     return par
+
+
+def test_a_parent_deleted_with_its_subtree_is_patched(oracle, tmp_path):
+    """flecs deletes the tables of a deleted parent's children with them (their ChildOf pair names a dead entity): the
+    system hears of the deleted tables, lets their batches die without touching the pointers, and does not rebuild."""
+    n, levels = 20_000, 6
+    lo = oracle.synth_level_offsets(n, levels)
+    par = oracle.synth_parents(lo)
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo[1])))
+    bounds = oracle.synth_aabb(n)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    victims = [int(lo[2]) + 3, int(lo[3]) + 7, int(lo[1]) + 1]  # parents on three levels, each with a subtree below
+    frames = [[], [(victims[0], 2, np.zeros(16, np.float32))], [],
+              [(victims[1], 2, np.zeros(16, np.float32)), (victims[2], 2, np.zeros(16, np.float32)),
+               (0, 0, oracle.compose([1, 2, 3], [0, 0, 0, 1], [1, 1, 1]))], []]
+    scene, out_c, out_g = tmp_path / "scene.bin", tmp_path / "cpu.bin", tmp_path / "gpu.bin"
+    write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
+    subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
+    subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
+    cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
+    gpu = read_out(out_g, n, len(frames), 1, oracle.T68, gpu=True)
+    for fi, ((cw, cl, _, rows, _), (gw, gl, rebuilds, g_rows, vis)) in enumerate(zip(cpu, gpu)):
+        with np.errstate(all="ignore"):
+            assert np.array_equal(gw["m"], cw["m"], equal_nan=True) and np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi}"
+        assert np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"]), f"frame {fi}: dirty bytes"
+        assert g_rows == rows, f"frame {fi}: {g_rows} rows on the device, {rows} in the CPU systems"
+        assert rebuilds == 1, f"frame {fi}: {rebuilds} rebuilds {vis[-1]}"
+        here = np.flatnonzero(cw["m"].any(axis=1) | cl["m"].any(axis=1))
+        exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[here]), np.ascontiguousarray(bounds[here]), planes)
+        assert np.array_equal(np.sort(vis[0]), here[np.flatnonzero(exp_vis[0])]), f"frame {fi}: visible set"
+    assert gpu[-1][4][-1][4] == 2 and gpu[-1][3] < n - 3, f"two patched frames, subtrees gone: {gpu[-1][4][-1]}, rows {gpu[-1][3]}"

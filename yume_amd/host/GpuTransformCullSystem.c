@@ -155,6 +155,8 @@ struct GpuTransformCullSystem {
     uint32_t level_fill[YH_MAX_LEVELS]; /* first free slot of every level's range */
     ecs_table_t** touched;        /* tables with one of the components that rows entered or left since the last frame */
     uint32_t n_touched, cap_touched;
+    ecs_table_t** deleted;        /* tables with one of the components deleted since the last frame: their batches die */
+    uint32_t n_deleted, cap_deleted;
     int need_full;                /* an event patch() cannot follow: a table deleted, too many tables touched */
     int walk_cache_valid;         /* cached_* describe the batches (false after a patch: the next walk rebuilds) */
     uint32_t* cached_slot;        /* per batch: slot_begin and parent_slot as the last rebuild assigned them */
@@ -814,7 +816,26 @@ static void note_structure(ecs_iter_t* it) {
 static void note_table(ecs_iter_t* it) {
     GpuTransformCullSystem* s = (GpuTransformCullSystem*)it->ctx;
     s->structure_dirty = 1;
-    if (it->event == EcsOnTableDelete) s->need_full = 1; /* a listed or cached table pointer may dangle now */
+    if (it->event != EcsOnTableDelete || s->need_full) return;
+    /* The pointer dangles from here on (and may be handed out again for another table): it leaves the list of touched
+     * tables, which patch() dereferences, and joins the list of deleted ones, which it only compares with. */
+    ecs_table_t* t = it->table;
+    uint32_t kept = 0;
+    for (uint32_t i = 0; i < s->n_touched; ++i)
+        if (s->touched[i] != t) s->touched[kept++] = s->touched[i];
+    s->n_touched = kept;
+    if (s->n_deleted && s->deleted[s->n_deleted - 1] == t) return; /* (one event per component the table holds) */
+    if (s->n_deleted == s->cap_deleted) {
+        const uint32_t cap = s->cap_deleted ? s->cap_deleted * 2 : 256;
+        ecs_table_t** g = cap > MAX_TOUCHED ? NULL : (ecs_table_t**)realloc(s->deleted, sizeof(ecs_table_t*) * cap);
+        if (!g) {
+            s->need_full = 1;
+            return;
+        }
+        s->deleted = g;
+        s->cap_deleted = cap;
+    }
+    s->deleted[s->n_deleted++] = t;
 }
 
 /* OnSet observers: the same events that run the components' onSet hooks */
@@ -1162,10 +1183,17 @@ static int patch(GpuTransformCullSystem* s) {
         for (uint32_t i = 0; i < s->n_touched; ++i)
             if (!nt || s->touched[nt - 1] != s->touched[i]) s->touched[nt++] = s->touched[i];
     }
-    s->last_patch_tables = nt;
-    if (!nt) return YH_OK;
-    PatchItem* items = (PatchItem*)calloc(nt, sizeof(PatchItem));
-    uint32_t* old_of = (uint32_t*)malloc(sizeof(uint32_t) * nt); /* per listed table: its batch, or UINT32_MAX */
+    uint32_t nd = 0; /* deleted tables, sorted, unique */
+    if (s->n_deleted) {
+        qsort(s->deleted, s->n_deleted, sizeof(ecs_table_t*), by_ptr);
+        for (uint32_t i = 0; i < s->n_deleted; ++i)
+            if (!nd || s->deleted[nd - 1] != s->deleted[i]) s->deleted[nd++] = s->deleted[i];
+    }
+    s->last_patch_tables = nt + nd;
+    if (!nt && !nd) return YH_OK;
+    PatchItem* items = (PatchItem*)calloc((size_t)nt + 1, sizeof(PatchItem));
+    uint32_t cap_items = nt + 1;
+    uint32_t* old_of = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)nt + 1)); /* per listed table: its batch, or UINT32_MAX */
     uint32_t* kids = NULL;  /* batches whose parent row moves inside its level */
     uint8_t* reloc = NULL;
     int32_t* new_level = NULL;
@@ -1183,6 +1211,34 @@ static int patch(GpuTransformCullSystem* s) {
     for (uint32_t b = 0; b < s->n_batches; ++b) {
         const Batch* bt = &s->batches[b];
         if (!bt->count || !bt->table) continue;
+        if (nd) { /* a batch of a deleted table dies (compared, never dereferenced); the pointer may be listed as well,
+                   * then as ANOTHER table that was given the same address: a new table to this system */
+            uint32_t dl = 0, dh = nd;
+            while (dl < dh) {
+                const uint32_t mid = (dl + dh) / 2;
+                if ((uintptr_t)s->deleted[mid] < (uintptr_t)bt->table) dl = mid + 1;
+                else dh = mid;
+            }
+            if (dl < nd && s->deleted[dl] == bt->table) {
+                if (ni == cap_items) {
+                    PatchItem* g = (PatchItem*)realloc(items, sizeof(PatchItem) * (size_t)cap_items * 2);
+                    if (!g) {
+                        rc = YH_ERR_OOM;
+                        goto done;
+                    }
+                    items = g;
+                    cap_items *= 2;
+                }
+                PatchItem gone;
+                memset(&gone, 0, sizeof gone);
+                gone.old_batch = b;
+                gone.new_batch = UINT32_MAX;
+                gone.src = bt->src;
+                gone.level = bt->level;
+                items[ni++] = gone;
+                continue;
+            }
+        }
         uint32_t lo = 0, hi = nt;
         while (lo < hi) {
             const uint32_t mid = (lo + hi) / 2;
@@ -1215,6 +1271,15 @@ static int patch(GpuTransformCullSystem* s) {
             if (!it.src) continue;                      /* no parent: the Up term does not match this table */
             if (!ecs_has_id(s->world, it.src, s->world_id)) goto not_a_patch; /* Up resolves further up, or not at all */
             it.level = -1; /* one below its parent's, found below (the parent may be a row of this very patch) */
+        }
+        if (ni == cap_items) {
+            PatchItem* g = (PatchItem*)realloc(items, sizeof(PatchItem) * (size_t)cap_items * 2);
+            if (!g) {
+                rc = YH_ERR_OOM;
+                goto done;
+            }
+            items = g;
+            cap_items *= 2;
         }
         items[ni++] = it;
     }
@@ -1256,6 +1321,7 @@ static int patch(GpuTransformCullSystem* s) {
             PatchItem* it = &items[i];
             int32_t lvl;
             uint32_t where, ps;
+            if (!it->count) continue; /* (a table that left or was deleted: its batch dies, nothing is placed) */
             if (it->src == s->root) lvl = 0;
             else if (map_get(&moved, it->src, &where)) {
                 if (!where) goto not_a_patch; /* the parent left */
@@ -1318,6 +1384,7 @@ static int patch(GpuTransformCullSystem* s) {
                 goto done;
             }
             items = g;
+            cap_items = ni + n_follow;
             for (uint32_t c = 0; c < s->n_batches; ++c) {
                 if (reloc[c] != 2) continue;
                 const Batch* bt = &s->batches[c];
@@ -1339,6 +1406,7 @@ static int patch(GpuTransformCullSystem* s) {
         }
     }
     for (uint32_t i = 0; i < ni; ++i) {
+        if (!items[i].count) continue;
         if (items[i].level < 0 || (uint32_t)items[i].level >= s->n_levels) goto not_a_patch; /* deeper than the scene's levels */
         need[items[i].level] += items[i].count;
     }
@@ -1504,7 +1572,7 @@ static void run(ecs_iter_t* it) {
         s->last_ms[5] = now_ms() - t_patch;
         if (rc == YH_OK) {
             s->structure_dirty = 0;
-            s->n_touched = 0;
+            s->n_touched = s->n_deleted = 0;
             s->cached_match_count = ecs_query_match_count(it->query);
             clean = 1;
             patched_rows_up = s->last_up_rows;
@@ -1527,7 +1595,7 @@ static void run(ecs_iter_t* it) {
     } else {
         s->batches_live = 0;
         s->structure_dirty = 0; /* (cleared first: what the walk below sees is what the flag stands for) */
-        s->n_touched = 0;
+        s->n_touched = s->n_deleted = 0;
         s->need_full = 0;
         if (s->skip_walks && restore_walk(s, it)) {
             ecs_iter_fini(it);
@@ -1970,6 +2038,7 @@ void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     if (s->slot_buf_pinned) yh_host_free(s->ctx, s->slot_buf);
     else free(s->slot_buf);
     free(s->touched);
+    free(s->deleted);
     free(s->mesh_table);
     free(s->mesh_vcount);
     free(s->mesh_index.e);

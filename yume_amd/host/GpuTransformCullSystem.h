@@ -82,9 +82,10 @@ int GpuTransformCullSystem_setIncremental(GpuTransformCullSystem* s, int on);
  * (an eighth of the level, at least 64; dead on the device: yh_scene_set_alive_range), the rows of a table that changed
  * take spare slots of its level, its old slots die, children of moved rows learn the new parent slot
  * (yh_upload_parent_range); a subtree re-parented to another depth takes the batches below it along to the spare slots
- * of their new levels.  No walk of the query, no re-sort, no column upload.  What a patch cannot follow - an entity
- * with children deleted (flecs deletes their tables), a subtree that would reach below the scene's deepest level, a
- * level's spare slots used up - falls back to the walk and the rebuild, which also compacts the slots again.
+ * of their new levels; the batches of tables flecs deleted (the children of a deleted parent) die without their
+ * pointers being touched.  No walk of the query, no re-sort, no column upload.  What a patch cannot follow - a subtree
+ * that would reach below the scene's deepest level, a level's spare slots used up, a quarter of the slots moving -
+ * falls back to the walk and the rebuild, which also compacts the slots again.
  * `patches` counts the frames that took this path.                                                             */
 int GpuTransformCullSystem_setPatching(GpuTransformCullSystem* s, int on);
 uint64_t GpuTransformCullSystem_patches(const GpuTransformCullSystem* s);
