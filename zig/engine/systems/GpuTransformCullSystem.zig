@@ -163,6 +163,15 @@ pub fn lastTimes() [6]f64 {
     return ms;
 }
 
+/// Frames whose structural change (entities created, deleted, re-parented) was followed by moving the rows of the
+/// tables that changed to spare slots, without a walk of the query or a rebuild; `setPatching(false)` rebuilds always.
+pub fn patches() u64 {
+    return if (state) |s| GpuTransformCullSystem_patches(s) else 0;
+}
+pub fn setPatching(on: bool) void {
+    _ = GpuTransformCullSystem_setPatching(state.?, @intFromBool(on));
+}
+
 /// Status of the last frame (system callbacks cannot return one), or of the last call above that failed.
 pub fn status() c_int {
     if (state) |s| {
