@@ -671,3 +671,33 @@ def test_a_parent_deleted_with_its_subtree_is_patched(oracle, tmp_path):
         exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[here]), np.ascontiguousarray(bounds[here]), planes)
         assert np.array_equal(np.sort(vis[0]), here[np.flatnonzero(exp_vis[0])]), f"frame {fi}: visible set"
     assert gpu[-1][4][-1][4] == 2 and gpu[-1][3] < n - 3, f"two patched frames, subtrees gone: {gpu[-1][4][-1]}, rows {gpu[-1][3]}"
+
+
+def test_dead_slots_are_reused_by_later_patches(oracle, tmp_path):
+    """A leaf that hops between two parents with some hundred children each moves ~600 rows per frame (both tables'
+    rows are placed anew); the runs of slots that die are handed out again, so forty such frames need no rebuild
+    although the level's spare slots would be gone after three."""
+    n, levels = 6000, 3
+    lo = np.array([0, 10, 30, n], np.uint32)
+    par = np.full(n, 0xFFFFFFFF, np.uint32)
+    par[10:30] = np.arange(20) // 2
+    par[30:] = 10 + (np.arange(n - 30) * 20 // (n - 30))  # ~300 children under each of the 20 parents of level 1
+    local = oracle.compose_batch(oracle.synth_trs(n, 10))
+    bounds = oracle.synth_aabb(n)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    hopper, a, b = n - 1, 10, 11
+    frames = [[]] + [[(hopper, 3, reparent_arg(a if k % 2 == 0 else b))] for k in range(40)] + [[]]
+    scene, out_c, out_g = tmp_path / "scene.bin", tmp_path / "cpu.bin", tmp_path / "gpu.bin"
+    write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
+    subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
+    subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
+    cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
+    gpu = read_out(out_g, n, len(frames), 1, oracle.T68, gpu=True)
+    for fi, ((cw, cl, _, rows, _), (gw, gl, rebuilds, g_rows, vis)) in enumerate(zip(cpu, gpu)):
+        with np.errstate(all="ignore"):
+            assert np.array_equal(gw["m"], cw["m"], equal_nan=True) and np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi}"
+        assert g_rows == rows == n
+        exp_vis, _ = oracle.cull(np.ascontiguousarray(cw), bounds, planes)
+        assert np.array_equal(np.sort(vis[0]), np.flatnonzero(exp_vis[0])), f"frame {fi}: visible set"
+    assert gpu[-1][2] == 1 and gpu[-1][4][-1][4] == 40, f"rebuilds {gpu[-1][2]}, (up, down, walks, skipped, patches) {gpu[-1][4][-1]}"

@@ -63,6 +63,10 @@ typedef struct Map {
     uint64_t cap; /* power of two */
 } Map;
 
+typedef struct SlotRun {
+    uint32_t first, count;
+} SlotRun;
+
 typedef struct BoundsEntry {
     ecs_entity_t key;
     float mm[6];
@@ -153,6 +157,8 @@ struct GpuTransformCullSystem {
     uint64_t n_slots;             /* slots of the device scene: rows + spare */
     uint32_t level_begin[YH_MAX_LEVELS + 1];
     uint32_t level_fill[YH_MAX_LEVELS]; /* first free slot of every level's range */
+    struct SlotRun* free_runs[YH_MAX_LEVELS]; /* per level: runs of slots that died (their table's rows moved away or left), reused before the tail */
+    uint32_t n_free[YH_MAX_LEVELS];
     ecs_table_t** touched;        /* tables with one of the components that rows entered or left since the last frame */
     uint32_t n_touched, cap_touched;
     ecs_table_t** deleted;        /* tables with one of the components deleted since the last frame: their batches die */
@@ -185,11 +191,14 @@ static int map_init(Map* m, uint64_t n) {
     return m->e ? 0 : -1;
 }
 
-static void map_put(Map* m, ecs_entity_t k, uint32_t v) {
+/* returns 1 if the key is new to the map */
+static int map_put(Map* m, ecs_entity_t k, uint32_t v) {
     uint64_t i = hash64(k) & (m->cap - 1);
     while (m->e[i].key && m->e[i].key != k) i = (i + 1) & (m->cap - 1);
+    const int fresh = m->e[i].key == 0;
     m->e[i].key = k;
     m->e[i].value = v;
+    return fresh;
 }
 
 /* keys[i] -> i for every non-zero key.  A map of a million entities is far larger than the caches and every insert a
@@ -451,6 +460,7 @@ static int rebuild(GpuTransformCullSystem* s) {
     level_offsets[n_levels] = slot;
     const uint64_t N = slot; /* slots of the device scene */
     memcpy(s->level_begin, level_offsets, sizeof(uint32_t) * (n_levels + 1));
+    memset(s->n_free, 0, sizeof s->n_free); /* (a rebuild compacts: no dead runs) */
     TRACE_STEP("sort by parent slot, slots");
 
     const uint32_t want_bounds = s->mesh_id ? YH_BOUNDS_MESH_TABLE : YH_BOUNDS_PER_ENTITY;
@@ -1149,6 +1159,7 @@ typedef struct PatchItem {
     int32_t col_w, col_l, level;
     ecs_entity_t src;
     uint32_t new_batch;
+    uint32_t first; /* the slots its rows take */
 } PatchItem;
 static int by_ptr(const void* a, const void* b) {
     const uintptr_t x = (uintptr_t) * (ecs_table_t* const*)a, y = (uintptr_t) * (ecs_table_t* const*)b;
@@ -1197,11 +1208,14 @@ static int patch(GpuTransformCullSystem* s) {
     uint32_t* kids = NULL;  /* batches whose parent row moves inside its level */
     uint8_t* reloc = NULL;
     int32_t* new_level = NULL;
+    SlotRun* plan[YH_MAX_LEVELS]; /* the levels' free runs as they will be after this patch (NULL: level not involved) */
+    uint32_t plan_n[YH_MAX_LEVELS], plan_fill[YH_MAX_LEVELS], plan_extra[YH_MAX_LEVELS];
+    memset(plan, 0, sizeof plan);
+    memset(plan_extra, 0, sizeof plan_extra);
     uint32_t n_kids = 0, cap_kids = 0;
     Map moved = {0}; /* entity -> 1 + index of the item whose new content holds it, 0: it leaves */
-    uint64_t rows_in = 0, rows_out = 0, need[YH_MAX_LEVELS];
+    uint64_t rows_in = 0, rows_out = 0;
     uint32_t ni = 0;
-    memset(need, 0, sizeof need);
     if (!items || !old_of) {
         rc = YH_ERR_OOM;
         goto done;
@@ -1408,10 +1422,51 @@ static int patch(GpuTransformCullSystem* s) {
     for (uint32_t i = 0; i < ni; ++i) {
         if (!items[i].count) continue;
         if (items[i].level < 0 || (uint32_t)items[i].level >= s->n_levels) goto not_a_patch; /* deeper than the scene's levels */
-        need[items[i].level] += items[i].count;
     }
-    for (uint32_t l = 0; l < s->n_levels; ++l)
-        if ((uint64_t)s->level_fill[l] + need[l] > s->level_begin[l + 1]) goto not_a_patch; /* the level's spare slots are used up */
+    /* Where the rows go: into a run of slots that died earlier (or dies in this very patch) if one is long enough -
+     * best fit -, else into the untouched tail of the level's range.  Planned on copies of the levels' lists: nothing
+     * has changed yet if a level turns out to be full. */
+    qsort(items, ni, sizeof(PatchItem), by_level); /* (parents before children; equal levels in any order) */
+    for (uint32_t i = 0; i < ni; ++i) {
+        if (items[i].old_batch != UINT32_MAX) plan_extra[s->batches[items[i].old_batch].level] += 1;
+        if (items[i].count) plan_extra[items[i].level] += 1; /* (a run that is split stays one run: no growth; counted for the level's sake) */
+    }
+    for (uint32_t l = 0; l < s->n_levels; ++l) {
+        if (!plan_extra[l]) continue;
+        plan[l] = (SlotRun*)malloc(sizeof(SlotRun) * ((size_t)s->n_free[l] + plan_extra[l] + 1));
+        if (!plan[l]) {
+            rc = YH_ERR_OOM;
+            goto done;
+        }
+        if (s->n_free[l]) memcpy(plan[l], s->free_runs[l], sizeof(SlotRun) * s->n_free[l]);
+        plan_n[l] = s->n_free[l];
+        plan_fill[l] = s->level_fill[l];
+    }
+    for (uint32_t i = 0; i < ni; ++i) {
+        if (items[i].old_batch == UINT32_MAX) continue;
+        const Batch* b = &s->batches[items[i].old_batch];
+        plan[b->level][plan_n[b->level]].first = b->slot_begin;
+        plan[b->level][plan_n[b->level]++].count = b->count;
+    }
+    for (uint32_t i = 0; i < ni; ++i) {
+        PatchItem* it = &items[i];
+        if (!it->count) continue;
+        const uint32_t l = (uint32_t)it->level;
+        uint32_t r = plan_n[l]; /* best fit: the shortest run that is long enough (first fit splinters the long runs) */
+        for (uint32_t q = 0; q < plan_n[l]; ++q)
+            if (plan[l][q].count >= it->count && (r == plan_n[l] || plan[l][q].count < plan[l][r].count)) r = q;
+        if (r < plan_n[l]) {
+            it->first = plan[l][r].first;
+            plan[l][r].first += it->count;
+            plan[l][r].count -= it->count;
+            if (!plan[l][r].count) plan[l][r] = plan[l][--plan_n[l]];
+        } else if ((uint64_t)plan_fill[l] + it->count <= s->level_begin[l + 1]) {
+            it->first = plan_fill[l];
+            plan_fill[l] += it->count;
+        } else {
+            goto not_a_patch; /* the level's spare slots are used up: the rebuild compacts */
+        }
+    }
     if ((s->slot_entries + rows_in) * 10 > s->slot_of.cap * 7) goto not_a_patch;          /* the entity -> slot map is filling up */
     if (rows_in > s->n_slots / 4) goto not_a_patch;                                       /* most of a level moves: a rebuild is cheaper */
     /* room for the new batches */
@@ -1439,13 +1494,19 @@ static int patch(GpuTransformCullSystem* s) {
         b->table = NULL;
         b->world_col = b->local_col = NULL;
     }
-    qsort(items, ni, sizeof(PatchItem), by_level); /* (parents before children; equal levels in any order) */
-    for (uint32_t i = 0; i < ni; ++i) { /* the rows take spare slots of their level */
+    for (uint32_t l = 0; l < s->n_levels; ++l) { /* the levels' lists of dead runs and tails as planned */
+        if (!plan[l]) continue;
+        SlotRun* old_runs = s->free_runs[l];
+        s->free_runs[l] = plan[l];
+        s->n_free[l] = plan_n[l];
+        s->level_fill[l] = plan_fill[l];
+        plan[l] = old_runs; /* (freed with the plan) */
+    }
+    for (uint32_t i = 0; i < ni; ++i) { /* the rows take their slots */
         PatchItem* it = &items[i];
         if (!it->count) continue;
-        const uint32_t bi = s->n_batches++, first = s->level_fill[it->level];
+        const uint32_t bi = s->n_batches++, first = it->first;
         it->new_batch = bi;
-        s->level_fill[it->level] += it->count;
         Batch* b = &s->batches[bi];
         memset(b, 0, sizeof *b);
         b->table = it->table;
@@ -1460,10 +1521,9 @@ static int patch(GpuTransformCullSystem* s) {
         const ecs_entity_t* ents = ecs_table_entities(it->table);
         memcpy(s->entity_of_slot + first, ents, sizeof(ecs_entity_t) * it->count);
         for (uint32_t r = 0; r < it->count; ++r) {
-            map_put(&s->slot_of, ents[r], first + r);
+            s->slot_entries += (uint64_t)map_put(&s->slot_of, ents[r], first + r); /* (a row that only moved keeps its entry) */
             s->batch_of[first + r] = bi;
         }
-        s->slot_entries += it->count;
         s->n += it->count;
         /* rows as flecs holds them, flags included (a new entity's LocalTransform is dirty: transform.zig:46-51; a
          * re-parented one keeps its flags: ecs.zig:470-477 sets none) */
@@ -1534,6 +1594,7 @@ done:
     free(reloc);
     free(new_level);
     free(moved.e);
+    for (uint32_t l = 0; l < YH_MAX_LEVELS; ++l) free(plan[l]);
     return rc;
 not_a_patch:
     free(items);
@@ -1542,6 +1603,7 @@ not_a_patch:
     free(reloc);
     free(new_level);
     free(moved.e);
+    for (uint32_t l = 0; l < YH_MAX_LEVELS; ++l) free(plan[l]);
     return 1;
 }
 
@@ -2039,6 +2101,7 @@ void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     else free(s->slot_buf);
     free(s->touched);
     free(s->deleted);
+    for (uint32_t l = 0; l < YH_MAX_LEVELS; ++l) free(s->free_runs[l]);
     free(s->mesh_table);
     free(s->mesh_vcount);
     free(s->mesh_index.e);
