@@ -198,13 +198,15 @@ def test_explicit_launch_plans_give_identical_results(ctx, oracle, plan):
 def test_planner_groups_small_levels_and_triples_large_ones(ctx, oracle):
     from yume_amd import Scene
 
-    for n, expect in ((1_000_000, [5, 7]), (12_500_000, [1, 4, 7]), (4096, [7])):
+    # (large trees are cut from the last level backwards: a level of 5M entities alone, launches of at most ~6.1M)
+    for n, expect in ((1_000_000, [5, 7]), (12_500_000, [3, 6, 7]), (4096, [7]), (4_000_000, [4, 7]), (8_000_000, [2, 5, 7]),
+                      (25_000_000, [2, 5, 6, 7])):
         lo = oracle.synth_level_offsets(n, 8)
         with Scene(ctx, n, n_levels=8, n_frusta=0, bounds_kind=0) as s:
             s.upload_hierarchy(oracle.synth_parents(lo), lo)
             assert [int(q[1]) for q in s.groups()] == expect
     # culling scenes small enough for the expansion to ride on the next frame's first launch: a lighter first launch
-    for n, expect in ((1_000_000, [4, 7]), (500_000, [5, 7]), (250_000, [7]), (12_500_000, [1, 4, 7])):
+    for n, expect in ((1_000_000, [4, 7]), (500_000, [5, 7]), (250_000, [7]), (12_500_000, [3, 6, 7])):
         lo = oracle.synth_level_offsets(n, 8)
         with Scene(ctx, n, n_levels=8, n_frusta=1) as s:
             s.upload_hierarchy(oracle.synth_parents(lo), lo)

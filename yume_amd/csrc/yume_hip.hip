@@ -511,6 +511,36 @@ static int plan_groups(yh_scene* s) {
     // 0..5 | 6..7, 500k 22.2 us for 0..5 | 6..7 against 23.4 for 0..6 | 7; a 250k scene stays one launch (13.9 us).
     const bool rides = s->desc.local_kind == YH_LOCAL_TRS && s->desc.bounds_kind != YH_BOUNDS_NONE &&
                        (s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES && s->tile_words <= 64u) && s->n > 320 * 1024;
+    // Large TRS trees (re-measured in round 2 over all 128 cuts at 4M, 8M, 12.5M and 25M entities,
+    // profiles/r02/plan_sweep_*.txt): from the LAST level backwards, a level of 5M entities or more is a launch of its
+    // own (the one-level kernel: no ancestors re-read), smaller levels go up to three to a launch while the launch stays
+    // under ~6.1M entities, and once the levels above sum to 1M or less they share one chain launch.  12.5M: 0..3 | 4..6
+    // | 7, 331.8 us (the forward triples 0..1 | 2..4 | 5..7: 334.8; best of the 128: 329.4); 4M: 0..4 | 5..7, 107.7
+    // (before 0..3 | 4 | 5..7: >= 109.3; best 106.3); 8M: 0..2 | 3..5 | 6..7 and 1M: 0..4 | 5..7 as before, both the best.
+    if (s->desc.local_kind == YH_LOCAL_TRS && !s->max_group_levels && s->n > (2u << 20) && L > 1) {
+        std::vector<LevelGroup> back;
+        uint32_t hi = L - 1;
+        for (;;) {
+            if (span(0, hi) <= (1u << 20) && hi + 1 <= (uint32_t)YH_MAX_GROUP) {  // the small levels at the top: one chain launch
+                LevelGroup g;
+                g.lo = 0;
+                g.hi = hi;
+                back.push_back(g);
+                break;
+            }
+            uint32_t lo = hi;
+            if (span(hi, hi) < 5000000ull)
+                while (lo > 0 && hi - lo + 1 < 3 && span(lo - 1, hi) <= 6100000ull) --lo;
+            LevelGroup g;
+            g.lo = lo;
+            g.hi = hi;
+            back.push_back(g);
+            if (lo == 0) break;
+            hi = lo - 1;
+        }
+        s->groups.assign(back.rbegin(), back.rend());
+        return YH_OK;
+    }
     uint32_t lo = 0;
     while (lo < L) {
         const uint64_t resident = (lo == 0 && rides) ? 128 * 1024 : 320 * 1024;
