@@ -107,7 +107,8 @@ __device__ __forceinline__ void load_row(const float* __restrict__ base, uint32_
 // by a consumer: measured against nt / plain / sc1 / sc0 sc1 / sc0 nt (profiles/r02/ab_store_policy.txt) cfg5's
 // kernel 4.543 -> 4.490 ms, cfg3's 0.367 -> 0.356, cfg4's 0.2842 -> 0.2824; plain stores 4.623 / 0.381 / 0.309.
 // One 64-bit row address, the plane as the instruction's immediate offset (as the compiler addresses store_row).
-// PACED (the flat kernels, whose waves do nothing but stream): sixteen stores issued back to back fill the CU's
+// PACED (the flat kernels of scenes that stream past the caches, whose waves do nothing but stream; cache-resident
+// flat scenes were 0.5-1.4 % slower paced - profiles/r02/ab_pace_small_flat.txt - and are not): sixteen stores issued back to back fill the CU's
 // memory pipeline and hold up the other waves' loads behind them; a few idle issue slots after each store let those
 // loads in between (profiles/r02/ab_store_pace.txt: s_nop 0 / 7 / 11 / 15, s_sleep 1 / 2 -> cfg5 4.510 / 4.490 /
 // 4.484 / 4.485 / 4.479 / 4.494 ms, cfg3 0.3601 / 0.3575 / 0.3569 / 0.3568 / 0.3584 / 0.3596).  Tree levels, whose
@@ -522,7 +523,7 @@ __device__ __forceinline__ void frame_trs_tile(const FrameArgs& a, const uint32_
         for (int q = 0; q < 16; ++q) w.v[q] = a.root[q];
     }
     w = m4_mul(w, m4_compose(in.t[0], in.t[1], in.t[2], in.t[3], in.t[4], in.t[5], in.t[6], in.t[7], in.t[8], in.t[9]));
-    if (valid) store_world_row<!HAS_BASE>(a.world, e, w.v);
+    if (valid) store_world_row<!HAS_BASE && BIG>(a.world, e, w.v);
     if (BOUNDS != 0) {
         uint32_t vmask = 0, bmask = 0;
         cull_entity<BOUNDS>(a, w, in.b, in.mesh, vmask, bmask);
