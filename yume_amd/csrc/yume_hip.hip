@@ -126,6 +126,7 @@ struct yh_scene {
     uint64_t big_tree = YH_BIG_TREE, big_flat = YH_BIG_FLAT;  // entities from which read-once inputs are streamed (A/B: env of the same names)
     bool lds_parents = false;  // one-level launches stage their parents in LDS (yh_scene_set_lds_parents / YH_LDS_PARENTS=1)
     bool use_cull_plan = true;  // group planes by normal when some share one (YH_NO_CULL_PLAN=1 in the environment: A/B runs)
+    uint32_t defer_first_max = 1u << 20;  // entities in a first launch that still carries the previous frame's expansion
     uint32_t max_mesh_id = 0;  // largest id ever uploaded (ids start out as 0): the table may not shrink below it
     float root[16];
     uint32_t root_dirty = 1;  // world.set(scene_root, WorldTransform{IDENTITY}) -> dirty (GameApp.zig:95)
@@ -458,6 +459,7 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
     if (const char* v = getenv("YH_BIG_TREE")) s->big_tree = strtoull(v, nullptr, 10);
     if (const char* v = getenv("YH_BIG_FLAT")) s->big_flat = strtoull(v, nullptr, 10);
     if (const char* v = getenv("YH_EXPAND_TILES")) s->expand_tiles = (uint32_t)strtoul(v, nullptr, 10);
+    if (const char* v = getenv("YH_DEFER_FIRST_MAX")) s->defer_first_max = (uint32_t)strtoul(v, nullptr, 10);
     ctx->scenes.push_back(s);
     *out = s;
     return YH_OK;
@@ -1567,10 +1569,11 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
         }
         // TRS scenes, frames enqueued without a host sync: leave the expansion to the next frame's first launch (or to
         // whatever reads the lists first).  For small scenes its own dependent launch is a tenth of the frame; larger
-        // trees still gain 1.5-2 % when their first launch is a small one (12.5M entities: 364.5 -> 359.1 us).  Flat
-        // large scenes keep k_expand: riding on their one big launch costs that kernel more than the boundary.
+        // trees still gain 1-2 % when their first launch is one of up to 1M entities, which is what the planner gives
+        // the top of a large tree (12.5M entities, first launch 740K: 331.7 -> 328.8 us; profiles/r02/ab_defer_first.txt).
+        // Flat large scenes keep k_expand: riding on their one big launch costs that kernel more than the boundary.
         const bool small_first = !s->groups.empty() && s->groups.size() > 1 &&
-                                 s->level_offsets[s->groups[0].hi + 1] - s->level_offsets[0] <= 320u * 1024u;
+                                 s->level_offsets[s->groups[0].hi + 1] - s->level_offsets[0] <= s->defer_first_max;
         const bool defer = !use_static && (flags & YH_FRAME_ASYNC) && s->desc.local_kind == YH_LOCAL_TRS &&
                            (x.self_count || small_first) && !(ktiming && s->timing_only == -1);
         if (defer) {
