@@ -484,9 +484,10 @@ def test_mesh_buckets_need_a_mesh_table(ctx, oracle):
         assert e.value.code == _lib.YH_ERR_STATE
 
 
-@pytest.mark.parametrize("n,levels", [(300_000, 6), (5000, 1), (1_000_000, 8)])
+@pytest.mark.parametrize("n,levels", [(300_000, 6), (5000, 1), (1_000_000, 8), (4_200_000, 8)])
 def test_async_frames_defer_their_expansion_and_give_the_same_lists(ctx, oracle, n, levels):
-    """YH_FRAME_ASYNC frames of small TRS scenes leave their list expansion to the next frame's first launch (or to the
+    """YH_FRAME_ASYNC frames of TRS scenes whose first launch is small (up to 1M entities: the 4.2M tree's levels 0..4,
+    with k_count's tile bases in between) leave their list expansion to the next frame's first launch (or to the
     first reader).  Whatever reads next — counts, a list, the object-data consumer, a plain yh_wait — has to see
     exactly the frame's own lists, boundary counts included, with the frusta changing from frame to frame."""
     from yume_amd import _lib
@@ -511,6 +512,7 @@ def test_async_frames_defer_their_expansion_and_give_the_same_lists(ctx, oracle,
             for j in range(1 + rnd % 3):  # one to three frames back to back, then the one that is checked
                 s.frame(np.concatenate(cams[: 1 + (rnd + j) % 4]), flags)
             s.frame(np.concatenate(cams[:nf]), flags)
+            assert "_x<" in s.group_kernel_names()[0]  # the first launch carried the frame before's expansion
             vis, bnd = expected(nf - 1)
             how = readers[rnd % len(readers)]
             if how == "object":
