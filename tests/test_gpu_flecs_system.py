@@ -291,7 +291,8 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
     no rebuild) and rebuilds otherwise; either way every row and every visible set equals the CPU systems' - and a
     burst of creations larger than a level's spare slots must fall back to the rebuild."""
     rng = np.random.default_rng(1000 + seed)
-    n0, levels, extra = 20_000, 6, 1500
+    n_frames = int(os.environ.get("YH_STRUCT_FRAMES", "26"))  # a soak: YH_STRUCT_FRAMES=200
+    n0, levels, extra = 20_000, 6, 1500 * max(1, n_frames // 26)
     n = n0 + extra
     lo0 = oracle.synth_level_offsets(n0, levels)
     par0 = oracle.synth_parents(lo0)
@@ -327,7 +328,6 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
         return max(depth[x] for x in subtree(e)) - depth[e]
 
     frames = [[], []]
-    n_frames = 26
     for fi in range(2, n_frames):
         edits = []
         kind_of_frame = rng.integers(0, 8)
