@@ -208,6 +208,11 @@ int yh_download_local_aos68(yh_scene* s, void* column, uint64_t first, uint64_t 
  * frame.  cap too small: YH_ERR_CAPACITY with *written = rows needed.  Any of the three outputs may be NULL.  */
 int yh_upload_local_rows_aos68(yh_scene* s, const uint32_t* slots, const void* rows, uint64_t count);
 int yh_upload_world_rows_aos68(yh_scene* s, const uint32_t* slots, const void* rows, uint64_t count);
+/* Rows that change slots on the device: both rows (matrices and dirty bytes) of src_slots[i] become the rows of
+ * dst_slots[i]; every source is read before any destination is written, so the lists may overlap.  For a host whose own
+ * copies are older than the scene's (frames ran with the results left on the device, §8f N2) and whose tables are now
+ * re-ordered - the GPU twin of flecs moving a row between tables on re-parenting (ecs.zig:470-477).               */
+int yh_move_rows(yh_scene* s, const uint32_t* src_slots, const uint32_t* dst_slots, uint64_t count);
 int yh_scene_track_changes(yh_scene* s, int enable);
 int yh_get_changed_count(yh_scene* s, uint64_t* n_changed);
 int yh_download_changed_aos68(yh_scene* s, uint32_t* slots, void* world_rows, void* local_rows, uint64_t cap,

@@ -517,3 +517,41 @@ def test_spare_slots_dead_slots_and_a_moved_row(ctx, oracle):
         moved = check("frame 2 (one entity moved)")
         assert np.array_equal(moved, [new_slot])
         assert check("frame 3").size == 0
+
+
+def test_rows_change_slots_on_the_device(ctx, oracle):
+    """yh_move_rows: both rows of src[i], flags included, become the rows of dst[i]; sources are read before any
+    destination is written (a rotation: every destination is another pair's source), rows outside dst keep theirs;
+    bad slots and TRS scenes are refused."""
+    from yume_amd import Scene, _lib
+
+    n = 70_001
+    rng = np.random.default_rng(21)
+    world, local = np.zeros(n, oracle.T68), np.zeros(n, oracle.T68)
+    for col in (world, local):
+        col["m"] = rng.standard_normal((n, 16)).astype(np.float32)
+        col["dirty"] = rng.integers(0, 2, n)
+    with Scene(ctx, n, n_levels=1, n_frusta=1, local_kind=_lib.YH_LOCAL_MAT4) as s:
+        s.upload_flat()
+        s.upload_world_aos68(world)
+        s.upload_local_aos68(local)
+        ring = rng.permutation(n)[:20_000].astype(np.uint32)          # src[i] -> src[i + 1]: all of them overlap
+        rest = np.setdiff1d(np.arange(n, dtype=np.uint32), ring)
+        src = np.concatenate([ring, rest[:300]])                      # plus plain moves onto slots nobody reads
+        dst = np.concatenate([np.roll(ring, -1), rest[300:600]])
+        s.move_rows(src, dst)
+        exp_w, exp_l = world.copy(), local.copy()
+        exp_w[dst], exp_l[dst] = world[src], local[src]
+        gw, gl = s.world_aos68(), s.local_aos68()
+        for got, exp, what in ((gw, exp_w, "world"), (gl, exp_l, "local")):
+            assert np.array_equal(got["m"].view(np.uint32), exp["m"].view(np.uint32)), what
+            assert np.array_equal(got["dirty"], exp["dirty"]), what + " flags"
+        s.move_rows(np.zeros(0, np.uint32), np.zeros(0, np.uint32))
+        for bad_src, bad_dst in (([n], [0]), ([0], [n])):
+            with pytest.raises(_lib.YumeHipError) as e:
+                s.move_rows(np.array(bad_src, np.uint32), np.array(bad_dst, np.uint32))
+            assert e.value.code == _lib.YH_ERR_BAD_ARG
+    with Scene(ctx, 100, n_levels=1, n_frusta=1) as t:
+        with pytest.raises(_lib.YumeHipError) as e:
+            t.move_rows(np.array([1], np.uint32), np.array([2], np.uint32))
+        assert e.value.code == _lib.YH_ERR_STATE

@@ -282,14 +282,17 @@ def test_the_system_reads_cameras_and_mesh_bounds_from_the_ecs(oracle, tmp_path)
         rebuilds_before = rebuilds
 
 
-@pytest.mark.parametrize("seed,ecs_inputs",  # more seeds: YH_STRUCT_SEEDS=40
-                         [(k, k % 4 == 3) for k in range(int(os.environ.get("YH_STRUCT_SEEDS", "4")))])
-def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cpu_systems(oracle, tmp_path, seed, ecs_inputs):
+@pytest.mark.parametrize("seed,ecs_inputs,stale_from",  # more seeds: YH_STRUCT_SEEDS=40
+                         [(k, k % 4 == 3, 5 if k % 4 == 1 else 0) for k in range(int(os.environ.get("YH_STRUCT_SEEDS", "4")))])
+def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cpu_systems(oracle, tmp_path, seed, ecs_inputs,
+                                                                                          stale_from):
     """Editor traffic (Editor.zig:590-636, GameApp.zig:204-215): entities created (under old parents, under parents
     created a frame earlier), leaves deleted, leaves and whole subtrees re-parented (same depth and other depths),
     parents with children deleted, mixed with matrix edits, frame after frame.  The system patches what it can (no walk,
     no rebuild) and rebuilds otherwise; either way every row and every visible set equals the CPU systems' - and a
-    burst of creations larger than a level's spare slots must fall back to the rebuild."""
+    burst of creations larger than a level's spare slots must fall back to the rebuild.  stale_from: results stay on the
+    device from that frame to the last but one (setReadback(0)): the patches then move rows on the device, flecs' columns
+    are compared again after the last frame has brought everything home, the visible sets every frame."""
     rng = np.random.default_rng(1000 + seed)
     n_frames = int(os.environ.get("YH_STRUCT_FRAMES", "26"))  # a soak: YH_STRUCT_FRAMES=200
     n0, levels, extra = 20_000, 6, 1500 * max(1, n_frames // 26)
@@ -411,10 +414,12 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
     env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
     if ecs_inputs:
         env["YFH_ECS_INPUTS"] = "1"
+    if stale_from:
+        env["YFH_READBACK_OFF_FROM"] = str(stale_from)
     subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
     cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
     gpu = read_out(out_g, n, len(frames), 2 if ecs_inputs else planes.shape[0], oracle.T68, gpu=True)
-    patches = rebuilds = 0
+    patches = rebuilds = stale_patches = 0
     cull_bounds, cull_planes = bounds, planes
     if ecs_inputs:  # the harness' Mesh components (entity e: mesh e % 4, none for 0) and its two Camera entities
         from yume_amd import synth
@@ -426,15 +431,18 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
         cull_planes = np.stack([synth.main_camera_planes(), synth.cascade_planes()[1]]).astype(np.float32).reshape(2, 24)
     for fi, ((cw, cl, _, rows, _), (gw, gl, g_rebuilds, g_rows, vis)) in enumerate(zip(cpu, gpu)):
         stats = f"(rows up, rows down, walks, skipped, patches) = {vis[-1]}, rebuilds {g_rebuilds}, edits {[(e, k) for e, k, _ in frames[fi]][:6]}"
+        host_current = not stale_from or fi < stale_from or fi + 1 == len(frames)  # flecs' columns are the CPU systems'
         with np.errstate(all="ignore"):
             bad = np.flatnonzero(~np.all((gw["m"] == cw["m"]) | (np.isnan(gw["m"]) & np.isnan(cw["m"])), axis=1))
-            assert bad.size == 0, f"frame {fi}: {bad.size} world matrices differ, first rows {bad[:8]} {stats}"
-            assert np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi}: local matrices {stats}"
-        assert np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"]), f"frame {fi}: dirty bytes {stats}"
+            assert bad.size == 0 or not host_current, f"frame {fi}: {bad.size} world matrices differ, first rows {bad[:8]} {stats}"
+            assert np.array_equal(gl["m"], cl["m"], equal_nan=True) or not host_current, f"frame {fi}: local matrices {stats}"
+        assert (np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"])) or not host_current, f"frame {fi}: dirty bytes {stats}"
         assert g_rows == rows, f"frame {fi}: {g_rows} rows on the device, {rows} in the CPU systems {stats}"
         structural = any(kind in (2, 3, 6) for _e, kind, _m in frames[fi])
         d_patch, d_rebuild = vis[-1][4] - patches, g_rebuilds - rebuilds
         patches, rebuilds = vis[-1][4], g_rebuilds
+        if stale_from and stale_from < fi < len(frames) - 1:
+            stale_patches += d_patch
         if fi and structural:
             assert d_patch + d_rebuild == 1, f"frame {fi}: a structural change is either patched or rebuilt {stats}"
         elif fi:
@@ -444,11 +452,12 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
         for f in range(cull_planes.shape[0]):
             assert np.array_equal(np.sort(vis[f]), here[np.flatnonzero(exp_vis[f])]), f"frame {fi} frustum {f}: visible set {stats}"
     assert patches >= 3 and rebuilds >= 1, f"the script was meant to exercise the patch path: {patches} patches, {rebuilds} rebuilds"
+    assert not stale_from or stale_patches >= 3, f"patches on device-resident rows were meant to happen: {stale_patches}"
 
 
 def test_readback_switched_off_and_on_again_after_patches(oracle, tmp_path):
     """Patches leave dead batches and dead slots behind; whole columns must still travel correctly when readback is
-    switched off afterwards (no patching then: structural changes rebuild) and on again."""
+    switched off afterwards (a structural change is then patched on the device's own rows) and on again."""
     n, levels = 30_000, 6
     rng = np.random.default_rng(5)
     lo = oracle.synth_level_offsets(n, levels)
@@ -468,7 +477,7 @@ def test_readback_switched_off_and_on_again_after_patches(oracle, tmp_path):
               [(int(e), 3, reparent_arg(int(p))) for e, p in zip(movers, new_par)],                   # patched
               [(int(e), 0, rnd_m()) for e in np.unique(rng.integers(0, int(lo[-2]), 200))],
               [(int(e), 1, rnd_m(50.0)) for e in np.unique(rng.integers(0, int(lo[-2]), 100))],       # readback off from here
-              [(int(e), 2, np.zeros(16, np.float32)) for e in doomed[15:]],                           # structural, stale host: rebuild
+              [(int(e), 2, np.zeros(16, np.float32)) for e in doomed[15:]],                           # structural, stale host: patched on the device
               [(-1, 1, oracle.compose([1, 2, 3], [0, 0.7071068, 0, 0.7071068], [2, 2, 2]))],
               []]                                                                                    # readback on: columns come home
     scene, out_c, out_g = tmp_path / "scene.bin", tmp_path / "cpu.bin", tmp_path / "gpu.bin"
@@ -604,10 +613,12 @@ def test_subtrees_moved_to_other_depths_patched_equals_rebuilt(oracle, tmp_path,
     scene = tmp_path / "scene.bin"
     write_scene(scene, lo, parent, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
     outs = {}
-    for mode in ("patched", "rebuilt"):
+    for mode in ("patched", "rebuilt", "patched, results left on the device from frame 3"):
         env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
         if mode == "rebuilt":
             env["YFH_NO_PATCH"] = "1"
+        elif mode != "patched":
+            env["YFH_READBACK_OFF_FROM"] = "3"
         out = tmp_path / f"{mode}.bin"
         subprocess.check_call([GPU, str(scene), str(out)], timeout=300, env=env)
         outs[mode] = read_out(out, n, len(frames), planes.shape[0], oracle.T68, gpu=True)
@@ -621,6 +632,18 @@ def test_subtrees_moved_to_other_depths_patched_equals_rebuilt(oracle, tmp_path,
         for f in range(planes.shape[0]):
             assert np.array_equal(np.sort(pvis[f]), np.sort(rvis[f])), f"frame {fi} frustum {f}: visible set {stats}"
     assert outs["patched"][-1][4][-1][4] >= 8, f"most structural frames were meant to be patched: {outs['patched'][-1][4][-1]}"
+    # subtrees that change depth while flecs' columns are stale: every row moves on the device (yh_move_rows); the
+    # visible sets are the device's every frame, the columns are compared once the last frame has brought them home
+    stale = outs["patched, results left on the device from frame 3"]
+    for fi, ((sw, sl, _sr, s_rows, svis), (rw, rl, _rr, r_rows, rvis)) in enumerate(zip(stale, outs["rebuilt"])):
+        assert s_rows == r_rows, f"frame {fi}: rows"
+        for f in range(planes.shape[0]):
+            assert np.array_equal(np.sort(svis[f]), np.sort(rvis[f])), f"frame {fi} frustum {f}: visible set, stale host {svis[-1]}"
+        if fi < 3 or fi + 1 == len(frames):
+            with np.errstate(all="ignore"):
+                assert np.array_equal(sw["m"], rw["m"], equal_nan=True) and np.array_equal(sl["m"], rl["m"], equal_nan=True), f"frame {fi}: matrices, stale host"
+            assert np.array_equal(sw["dirty"], rw["dirty"]) and np.array_equal(sl["dirty"], rl["dirty"]), f"frame {fi}: dirty bytes, stale host"
+    assert stale[-1][4][-1][4] >= 8, f"most structural frames were meant to be patched on the device: {stale[-1][4][-1]}"
 
 
 def alive_at(frames, upto, n0, parent):

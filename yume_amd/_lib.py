@@ -115,6 +115,7 @@ SIGNATURES = {
     "yh_scene_set_kernel_timing_period": (_int, [_vp, _u32]),
     "yh_upload_local_rows_aos68": (_int, [_vp, _vp, _vp, _u64]),
     "yh_upload_world_rows_aos68": (_int, [_vp, _vp, _vp, _u64]),
+    "yh_move_rows": (_int, [_vp, _vp, _vp, _u64]),
     "yh_scene_track_changes": (_int, [_vp, _int]),
     "yh_get_changed_count": (_int, [_vp, C.POINTER(_u64)]),
     "yh_download_changed_aos68": (_int, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),

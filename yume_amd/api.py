@@ -299,6 +299,13 @@ class Scene:
         assert slots.shape == rows.shape
         self._ck(L.lib().yh_upload_world_rows_aos68(self._h, _ptr(slots), _ptr(rows), slots.size))
 
+    def move_rows(self, src_slots, dst_slots):
+        """Both rows of src_slots[i] become the rows of dst_slots[i], on the device (sources read first)."""
+        src = np.ascontiguousarray(src_slots, np.uint32)
+        dst = np.ascontiguousarray(dst_slots, np.uint32)
+        assert src.shape == dst.shape
+        self._ck(L.lib().yh_move_rows(self._h, _ptr(src), _ptr(dst), src.size))
+
     def track_changes(self, enable=True):
         self._ck(L.lib().yh_scene_track_changes(self._h, int(bool(enable))))
 

@@ -919,6 +919,43 @@ extern "C" int yh_upload_world_rows_aos68(yh_scene* s, const uint32_t* slots, co
     return upload_rows(s, "yh_upload_world_rows_aos68", slots, rows, count, s ? s->world : nullptr, s ? s->wdirty : nullptr);
 }
 
+// Rows that change slots ON THE DEVICE (a host whose own copies are older than the scene's: frames ran without readback
+// and now its tables are re-ordered): WorldTransform and LocalTransform rows, flags included, of src_slots[i] become
+// the rows of dst_slots[i].  Every source row is read before any destination row is written, so the two lists may overlap.
+extern "C" int yh_move_rows(yh_scene* s, const uint32_t* src_slots, const uint32_t* dst_slots, uint64_t count) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_move_rows: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    if (s->desc.local_kind != YH_LOCAL_MAT4) return fail(ctx, YH_ERR_STATE, "yh_move_rows: scene holds TRS locals");
+    if (count == 0) return YH_OK;
+    ARG_TRY(ctx, src_slots && dst_slots, "yh_move_rows: NULL argument");
+    ARG_TRY(ctx, count <= s->n, "yh_move_rows: more rows than the scene has slots");
+    for (uint64_t i = 0; i < count; ++i)
+        if (src_slots[i] >= s->n || dst_slots[i] >= s->n)
+            return fail(ctx, YH_ERR_BAD_ARG, "yh_move_rows: pair %llu (%u -> %u) names a slot >= n_entities", (unsigned long long)i,
+                        src_slots[i], dst_slots[i]);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_scene(s)) return rc;
+    // staging: every row of one component (68 B), then the two slot lists
+    if (int rc = ensure_staging(s, count * 76)) return rc;
+    uint32_t* d_src = (uint32_t*)((char*)s->staging + count * 68);
+    uint32_t* d_dst = d_src + count;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(d_src, src_slots, count * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, dst_slots, count * 4, hipMemcpyHostToDevice, st));
+    const dim3 grid(cdiv(count, YH_BLOCK));
+    for (int k = 0; k < 2; ++k) {
+        float* planes = k ? s->lmat : s->world;
+        uint8_t* dirty = k ? s->ldirty : s->wdirty;
+        hipLaunchKernelGGL(k_soa_to_aos68, grid, dim3(YH_BLOCK), 0, st, (const float*)planes, (const uint8_t*)dirty, (uint64_t)0, count,
+                           (uint32_t*)s->staging, (const uint32_t*)d_src);
+        hipLaunchKernelGGL(k_aos68_to_soa, grid, dim3(YH_BLOCK), 0, st, (const uint32_t*)s->staging, count, planes, dirty, (uint64_t)0,
+                           (const uint32_t*)d_dst);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));  // the lists are the caller's
+    return YH_OK;
+}
+
 extern "C" int yh_scene_track_changes(yh_scene* s, int enable) {
     if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_scene_track_changes: scene is NULL");
     yh_ctx* ctx = s->ctx;

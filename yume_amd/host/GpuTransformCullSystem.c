@@ -153,7 +153,7 @@ struct GpuTransformCullSystem {
     /* Small structural changes without a rebuild (patch(), below).  Every level's range of slots ends in spare slots,
      * dead on the device (yh_scene_set_alive_range); the observers list the tables rows entered or left; the rows of
      * such a table move to spare slots of its level, its old slots die. */
-    int patching;                 /* default on; needs incremental mode, readback, trusted observers */
+    int patching;                 /* default on; needs incremental mode and trusted observers */
     uint64_t n_slots;             /* slots of the device scene: rows + spare */
     uint32_t level_begin[YH_MAX_LEVELS + 1];
     uint32_t level_fill[YH_MAX_LEVELS]; /* first free slot of every level's range */
@@ -1216,6 +1216,12 @@ static int patch(GpuTransformCullSystem* s) {
     Map moved = {0}; /* entity -> 1 + index of the item whose new content holds it, 0: it leaves */
     uint64_t rows_in = 0, rows_out = 0;
     uint32_t ni = 0;
+    /* Frames ran without readback: the device holds the newer rows.  A row that was on the device changes slots THERE
+     * (yh_move_rows); only rows of entities the scene has never held come from the flecs columns. */
+    const int dev_newer = s->host_stale;
+    uint32_t *mv_src = NULL, *mv_dst = NULL, *fresh_slots = NULL;
+    uint8_t *fresh_w = NULL, *fresh_l = NULL;
+    uint64_t n_mv = 0, n_fresh = 0;
     if (!items || !old_of) {
         rc = YH_ERR_OOM;
         goto done;
@@ -1482,6 +1488,36 @@ static int patch(GpuTransformCullSystem* s) {
         s->cap_batches = cap;
     }
 
+    if (dev_newer) { /* old slot -> new slot of every row the device holds; the others are copied out of their tables */
+        mv_src = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(rows_in + 1));
+        mv_dst = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(rows_in + 1));
+        fresh_slots = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(rows_in + 1));
+        fresh_w = (uint8_t*)malloc((size_t)(rows_in + 1) * ROW);
+        fresh_l = (uint8_t*)malloc((size_t)(rows_in + 1) * ROW);
+        if (!mv_src || !mv_dst || !fresh_slots || !fresh_w || !fresh_l) {
+            rc = YH_ERR_OOM;
+            goto done;
+        }
+        for (uint32_t i = 0; i < ni; ++i) {
+            const PatchItem* it = &items[i];
+            if (!it->count) continue;
+            const ecs_entity_t* ents = ecs_table_entities(it->table);
+            const uint8_t* wc = (const uint8_t*)ecs_table_get_column(it->table, it->col_w, 0);
+            const uint8_t* lc = (const uint8_t*)ecs_table_get_column(it->table, it->col_l, 0);
+            for (uint32_t r = 0; r < it->count; ++r) {
+                uint32_t os;
+                if (slot_lookup(s, ents[r], &os)) {
+                    mv_src[n_mv] = os;
+                    mv_dst[n_mv++] = it->first + r;
+                } else {
+                    fresh_slots[n_fresh] = it->first + r;
+                    memcpy(fresh_w + n_fresh * ROW, wc + (size_t)r * ROW, ROW);
+                    memcpy(fresh_l + n_fresh * ROW, lc + (size_t)r * ROW, ROW);
+                    ++n_fresh;
+                }
+            }
+        }
+    }
     /* from here on the state changes: an error leaves it to the next frame's rebuild (the caller sees to that) */
     for (uint32_t i = 0; i < ni; ++i) { /* the old slots die */
         if (items[i].old_batch == UINT32_MAX) continue;
@@ -1502,6 +1538,7 @@ static int patch(GpuTransformCullSystem* s) {
         s->level_fill[l] = plan_fill[l];
         plan[l] = old_runs; /* (freed with the plan) */
     }
+    if (n_mv && (rc = yh_move_rows(s->scene, mv_src, mv_dst, n_mv)) != YH_OK) goto done; /* (sources read first: a new slot may be another row's old one) */
     for (uint32_t i = 0; i < ni; ++i) { /* the rows take their slots */
         PatchItem* it = &items[i];
         if (!it->count) continue;
@@ -1527,11 +1564,13 @@ static int patch(GpuTransformCullSystem* s) {
         s->n += it->count;
         /* rows as flecs holds them, flags included (a new entity's LocalTransform is dirty: transform.zig:46-51; a
          * re-parented one keeps its flags: ecs.zig:470-477 sets none) */
-        if ((rc = yh_scene_set_alive_range(s->scene, first, it->count, 1)) != YH_OK ||
-            (rc = yh_upload_world_aos68(s->scene, b->world_col, first, it->count)) != YH_OK ||
-            (rc = yh_upload_local_aos68(s->scene, b->local_col, first, it->count)) != YH_OK)
-            goto done;
-        s->last_up_rows += 2u * it->count;
+        if ((rc = yh_scene_set_alive_range(s->scene, first, it->count, 1)) != YH_OK) goto done;
+        if (!dev_newer) {
+            if ((rc = yh_upload_world_aos68(s->scene, b->world_col, first, it->count)) != YH_OK ||
+                (rc = yh_upload_local_aos68(s->scene, b->local_col, first, it->count)) != YH_OK)
+                goto done;
+            s->last_up_rows += 2u * it->count;
+        }
         if (s->scene_bounds_kind == YH_BOUNDS_MESH_TABLE) {
             if (s->bounds_stale || !s->mesh_index.e) continue; /* every id is about to be read afresh anyway */
             /* mesh ids of the moved rows; a mesh seen for the first time extends the table (which goes up first) */
@@ -1561,6 +1600,12 @@ static int patch(GpuTransformCullSystem* s) {
             free(planes);
             if (rc != YH_OK) goto done;
         }
+    }
+    if (n_fresh) { /* entities the scene sees for the first time: their rows as flecs holds them */
+        if ((rc = yh_upload_world_rows_aos68(s->scene, fresh_slots, fresh_w, n_fresh)) != YH_OK ||
+            (rc = yh_upload_local_rows_aos68(s->scene, fresh_slots, fresh_l, n_fresh)) != YH_OK)
+            goto done;
+        s->last_up_rows += 2u * n_fresh;
     }
     for (uint32_t i = 0; i < ni; ++i) { /* parent slots of the moved rows (their parent may have moved in this patch too) */
         const PatchItem* it = &items[i];
@@ -1594,6 +1639,11 @@ done:
     free(reloc);
     free(new_level);
     free(moved.e);
+    free(mv_src);
+    free(mv_dst);
+    free(fresh_slots);
+    free(fresh_w);
+    free(fresh_l);
     for (uint32_t l = 0; l < YH_MAX_LEVELS; ++l) free(plan[l]);
     return rc;
 not_a_patch:
@@ -1603,6 +1653,11 @@ not_a_patch:
     free(reloc);
     free(new_level);
     free(moved.e);
+    free(mv_src);
+    free(mv_dst);
+    free(fresh_slots);
+    free(fresh_w);
+    free(fresh_l);
     for (uint32_t l = 0; l < YH_MAX_LEVELS; ++l) free(plan[l]);
     return 1;
 }
@@ -1626,7 +1681,7 @@ static void run(ecs_iter_t* it) {
                 it->query && ecs_query_match_count(it->query) == s->cached_match_count;
     s->last_up_rows = 0;
     s->last_patch_tables = 0;
-    if (!clean && s->patching && s->incremental && s->readback && !s->host_stale && s->skip_walks && s->trust_observers &&
+    if (!clean && s->patching && s->incremental && s->skip_walks && s->trust_observers &&
         !s->need_full && s->scene && s->cached_n && s->batches_live && it->query) {
         /* rows entered or left a few tables: move just those (no walk of the query, no rebuild) */
         const double t_patch = now_ms();
