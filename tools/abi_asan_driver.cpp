@@ -230,6 +230,16 @@ int main() {
         CK(yh_frame(s, nullptr, 0, 0));
         CK(yh_get_changed_count(s, &changed));
         EXPECT(changed == n);
+        {   // rows that change slots on the device: a rotation of three slots, and refused arguments
+            const uint32_t src[3] = {5, 6, 7}, dst[3] = {6, 7, 5}, bad[1] = {n};
+            std::vector<unsigned char> before(n * 68), after(n * 68);
+            CK(yh_download_world_aos68(s, before.data(), 0, n));
+            CK(yh_move_rows(s, src, dst, 3));
+            CK(yh_download_world_aos68(s, after.data(), 0, n));
+            for (int i = 0; i < 3; ++i) EXPECT(memcmp(&after[dst[i] * 68], &before[src[i] * 68], 64) == 0);
+            EXPECT(yh_move_rows(s, bad, dst, 1) == YH_ERR_BAD_ARG);
+            CK(yh_move_rows(s, nullptr, nullptr, 0));
+        }
         yh_scene_destroy(s);
     }
     // ---- one-rank communicator: both forms of the draw-list gather ----
