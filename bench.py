@@ -334,6 +334,8 @@ def run_workload(job, name, steps, warmup, headline, entities=0):
 
     collective = "none"
     gather = world_size > 1 or args.force_comm
+    if gather and not os.environ.get("YUME_BENCH_OWN_LISTS"):  # the gathered lists hold this GPU's part: its own lists are
+        flags |= _lib.YH_FRAME_LISTS_ON_DEMAND                   # expanded only if somebody reads them (A/B: tools/ab_lists_on_demand.sh)
     if world_size == 1 and args.force_comm:
         if not job.comm_up:
             with stdout_to_stderr():

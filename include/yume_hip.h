@@ -88,6 +88,10 @@ typedef struct yh_scene_desc {
                                      scenes (<= ~1M entities) leave the frame's list expansion to the next frame's first
                                      launch, or to the first call that reads the lists: results are the same */
 #define YH_FRAME_ORDERED     0x8u /* accepted, no effect: draw lists are ALWAYS in ascending entity order        */
+#define YH_FRAME_LISTS_ON_DEMAND 0x10u /* with YH_FRAME_ASYNC: this frame's own draw lists are expanded only if somebody
+                                     reads them (counts, a list, a consumer, yh_wait) before the next frame starts; the
+                                     next frame otherwise drops them unexpanded.  For frames whose visibility words go
+                                     to yh_allgather_draw_lists_async, whose gathered lists already hold this GPU's part */
 
 typedef struct yh_timing {
     float last_frame_ms;    /* device time of the most recent frame (hipEvent; 0 unless kernel timing is on) */

@@ -55,9 +55,12 @@ def test_rccl_one_rank_allgather(oracle):
             assert np.array_equal(s.allgather_draw_lists()[0], counts[:2])
 
 
-def test_rccl_one_rank_allgather_without_host_sync(oracle):
+@pytest.mark.parametrize("on_demand", [False, True])
+def test_rccl_one_rank_allgather_without_host_sync(oracle, on_demand):
     """The pipelined exchange (visibility words all-gathered on the collective stream, expanded on a third stream):
-    same lists as the scene's own, frame after frame, with and without host syncs in between."""
+    same lists as the scene's own, frame after frame, with and without host syncs in between.  on_demand: the frames
+    leave their own lists unexpanded (YH_FRAME_LISTS_ON_DEMAND, what bench.py's multi-GPU step passes): the gather needs
+    only the words, and the scene's own lists, read after it, are still the last frame's."""
     from yume_amd import Context, Scene, _lib
 
     n = 300_000
@@ -69,7 +72,7 @@ def test_rccl_one_rank_allgather_without_host_sync(oracle):
         with Scene(c, n, n_levels=6, n_frusta=2, id_base=11) as s:
             s.upload_hierarchy(par, lo)
             s.fill_synthetic()
-            flags = _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC
+            flags = _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC | (_lib.YH_FRAME_LISTS_ON_DEMAND if on_demand else 0)
             for k in range(21):  # back-to-back frames with different second frusta: each gather must see its own frame
                 # (21 rounds of 1-2 frames: the ring of word sets wraps several times)
                 planes = np.concatenate([cams[0], cams[1 + k % 2]])

@@ -529,6 +529,67 @@ def test_async_frames_defer_their_expansion_and_give_the_same_lists(ctx, oracle,
                 assert np.array_equal(s.draw_list(f), np.flatnonzero(vis[f]).astype(np.uint32)), (rnd, how, f)
 
 
+@pytest.mark.parametrize("n,levels", [(200_000, 5), (4_300_000, 1), (4_200_000, 8)])
+def test_lists_on_demand_frames(ctx, oracle, n, levels):
+    """YH_FRAME_LISTS_ON_DEMAND (frames whose words go to the gather): a frame nobody reads runs neither k_count nor
+    k_expand and is dropped by the next frame; one that is read gives exactly its own lists, counts and boundary counts
+    (the boundary counters rotate through three sets that k_expand normally zeroes: some entities sit on a plane here, so
+    a set that was not zeroed would show); ordinary deferred frames after a dropped one carry no stale expansion."""
+    from yume_amd import _lib
+
+    lo, par, trs, bounds = make_scene(oracle, n, levels)
+    n = trs.shape[1]
+    exp_w = oracle.frame_trs(trs, par, lo, n_threads=8)
+    # a plane x >= -d that the box of some entity touches (t = s + r within 1e-5 of 0): boundary cases in every frame that uses it
+    touching = None
+    for e in range(0, n, max(1, n // 200)):
+        m, b = exp_w["m"][e].astype(np.float64), bounds[e].astype(np.float64)
+        c, h = 0.5 * (b[:3] + b[3:]), 0.5 * (b[3:] - b[:3])
+        d = -((c[0] * m[0] + c[1] * m[4] + c[2] * m[8] + m[12]) + (abs(m[0]) * h[0] + abs(m[4]) * h[1] + abs(m[8]) * h[2]))
+        cand = np.array([[1, 0, 0, d], [-1, 0, 0, 1e6], [0, 1, 0, 1e6], [0, -1, 0, 1e6], [0, 0, 1, 1e6], [0, 0, -1, 1e6]],
+                        np.float32).reshape(1, 24)
+        if oracle.cull(exp_w[e:e + 1], bounds[e:e + 1], cand)[1][0][0]:
+            touching = cand
+            break
+    assert touching is not None, "no entity could be put on a plane"
+    cams = [oracle.main_camera_planes().reshape(1, 24), touching, oracle.cascade_planes()[1:2]]
+    expect = {}
+
+    def expected(key):
+        if key not in expect:
+            expect[key] = oracle.cull(exp_w, bounds, np.concatenate([cams[k] for k in key]), n_threads=8)
+        return expect[key]
+
+    def check(s, key):
+        vis, bnd = expected(key)
+        counts, bcounts = s.counts()
+        for f in range(len(key)):
+            assert counts[f] == np.count_nonzero(vis[f]) and bcounts[f] == np.count_nonzero(bnd[f]), (key, f, counts, bcounts)
+            assert np.array_equal(s.draw_list(f), np.flatnonzero(vis[f]).astype(np.uint32)), (key, f)
+
+    demand = _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC | _lib.YH_FRAME_LISTS_ON_DEMAND
+    plain = _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC
+    with gpu_scene(ctx, lo, par, trs, bounds, 2) as s:
+        n_groups = len(s.groups())
+        for k in range(75):  # unread frames, the touching plane among them; the ring of 64 counter sets wraps
+            s.frame(np.concatenate([cams[k % 3], cams[(k + 1) % 3]]), demand)
+            # the transform launches alone; every 32nd frame one small launch zeroes the next 32 sets of boundary counters
+            assert s.timings()["n_launches"] == n_groups + (1 if k % 32 == 0 else 0), k
+        s.frame(np.concatenate([cams[1], cams[0]]), demand)
+        check(s, (1, 0))
+        check(s, (1, 0))  # a second read finds the same lists
+        assert np.count_nonzero(expected((1, 0))[1][0]) >= 1, "the scene was meant to hold boundary cases"
+        for rnd in range(4):  # dropped frames between ordinary deferred ones, read every other round
+            s.frame(cams[2], demand)
+            s.frame(np.concatenate([cams[rnd % 3], cams[1]]), plain)
+            s.frame(np.concatenate([cams[1], cams[(rnd + 1) % 3]]), plain if rnd % 2 else demand)
+            check(s, (1, (rnd + 1) % 3))
+        s.frame(cams[1], demand)
+        ctx.wait()  # a wait alone leaves the lists obtainable
+        check(s, (1,))
+        assert_same_values(s.world_soa(), exp_w["m"].T, "world")
+
+
 def test_boundary_cases_are_counted(ctx, oracle):
     """Entities placed exactly on / within 1e-5 of a plane are reported in boundary_counts."""
     from yume_amd import Scene

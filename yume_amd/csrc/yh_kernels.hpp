@@ -968,6 +968,13 @@ __global__ __launch_bounds__(YH_BLOCK) void k_clear_dirty(uint32_t* __restrict__
     }
 }
 
+// Boundary-counter sets first .. first + n_sets - 1 (mod ring) to zero by plain stores: what k_expand does for one set
+// per frame, done for many frames at once when frames leave their lists unexpanded (YH_FRAME_LISTS_ON_DEMAND).
+__global__ __launch_bounds__(YH_BLOCK) void k_zero_sets(uint32_t* __restrict__ sets, uint32_t first, uint32_t n_sets, uint32_t ring) {
+    const uint32_t t = threadIdx.x;  // YH_BLOCK threads = 32 sets of YH_K_MAX_FRUSTA (8) words
+    if (t < n_sets * 8u) sets[((first + t / 8u) % ring) * 8u + (t & 7u)] = 0u;
+}
+
 __global__ __launch_bounds__(YH_BLOCK) void k_fill_u8(uint8_t* __restrict__ p, uint8_t v, uint64_t first, uint64_t count) {
     const uint64_t i = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;
     if (i < count) p[first + i] = v;

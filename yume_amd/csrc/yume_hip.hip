@@ -25,6 +25,11 @@ static_assert(YH_MAX_FRUSTA == YH_K_MAX_FRUSTA, "header / kernel frustum limits 
 
 // yh_download_changed_rows_aos68: rows gathered per kernel, copies per kernel, smallest copy worth an event
 #define YH_DL_ROWS_MAX (4ull << 20)
+// Boundary counters: frame k adds to set k % YH_BSETS; its k_expand reports the set and zeroes set k + 2 (the frame in
+// between may already be adding to set k + 1 when a deferred expansion runs).  Frames that leave their lists unexpanded
+// (YH_FRAME_LISTS_ON_DEMAND) zero YH_BZERO_AHEAD sets ahead at a time instead, one small launch per that many frames.
+#define YH_BSETS 64u
+#define YH_BZERO_AHEAD 32u
 #define YH_DL_PIECES 16
 #define YH_DL_PIECE_ROWS_MIN 32768ull
 
@@ -81,12 +86,16 @@ struct yh_scene {
     uint32_t n_segs = 0;              // k_count segments (4096 words each); tile-count rows hold n_tiles + n_segs words
     uint32_t* h_counts = nullptr;     // host-mapped: written by k_expand ([f] totals, [8+f] boundary counts)
     uint32_t* h_counts_dev = nullptr; // device address of h_counts
-    uint32_t bset = 0;                // which of the three boundary-counter sets this frame uses
+    uint32_t bset = 0;                // which of the YH_BSETS boundary-counter sets this frame uses
+    uint32_t* bsets = nullptr;        // [YH_BSETS][YH_MAX_FRUSTA]
+    uint32_t bzero_ahead = 0;         // upcoming frames whose set "two ahead" a bulk k_zero_sets has already zeroed
     uint8_t* viscnt_alt = nullptr;    // byte counts of the other sets of visibility words: [YH_MASK_SETS-1][n_frusta][cnt_stride]
     // Deferred expansion (TRS scenes of at most YH_SELF_COUNT_TILES tiles, YH_FRAME_ASYNC frames): the frame's
     // k_expand is not launched; the first launch of the next frame carries it (k_frame_*_x), or the next
     // synchronising / list-reading call launches it on its own.
     bool exp_pending = false;
+    bool pend_demand = false;  // the pending expansion is wanted only if somebody reads the lists (YH_FRAME_LISTS_ON_DEMAND)
+    bool pend_count = false;   // ... and its tile bases (k_count) have not been computed either
     ExpandArgs pend;
     uint32_t pend_frusta = 0;
     // change tracking (Mat4 scenes, yh_scene_track_changes): mask of rows a frame touched -> ascending slot list
@@ -321,7 +330,7 @@ static void scene_free(yh_scene* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->ctx->stream_c) (void)hipStreamSynchronize(s->ctx->stream_c);
-    void* ptrs[] = {s->trs, s->lmat, s->world, s->parent, s->bounds, s->mesh_id, s->ldirty, s->wdirty, s->counts,
+    void* ptrs[] = {s->trs, s->lmat, s->world, s->parent, s->bounds, s->mesh_id, s->ldirty, s->wdirty, s->counts, s->bsets,
                     s->staging, s->d_all_counts, s->chg, s->chg_list, s->chg_list_l, s->alive};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -411,6 +420,7 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
     s->cnt_stride = (s->n_chunks + 15u) & ~15u;
     s->vis_bytes = (4 * YH_MAX_FRUSTA + tile_words) * 4 + F_alloc * s->n_chunks * 8 + F_alloc * s->cnt_stride + 16;
     alloc((void**)&s->counts, s->vis_bytes);
+    alloc((void**)&s->bsets, (uint64_t)YH_BSETS * YH_MAX_FRUSTA * 4);
     if (e == hipSuccess) {
         s->tilecnt = s->counts + 4 * YH_MAX_FRUSTA;  // [0,8) totals, [8,16) and [16,24) boundary counters (two parities)
         s->vismask = (uint64_t*)(s->tilecnt + tile_words);
@@ -433,6 +443,7 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
     if (e == hipSuccess) e = hipMemsetAsync(s->ldirty, 1, S, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->wdirty, 1, S, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s->counts, 0, s->vis_bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s->bsets, 0, (uint64_t)YH_BSETS * YH_MAX_FRUSTA * 4, ctx->stream);
     // every entity starts with mesh 0: a frame or a consumer that runs before yh_upload_mesh_ids covered every entity
     // indexes the table, the vertex counts and the bucket histogram in bounds (hipMalloc does not zero)
     if (e == hipSuccess && s->mesh_id) e = hipMemsetAsync(s->mesh_id, 0, S * 4, ctx->stream);
@@ -478,6 +489,11 @@ static int check_range(yh_scene* s, const char* who, uint64_t first, uint64_t co
 static int flush_expand(yh_scene* s) {
     if (!s->exp_pending) return YH_OK;
     s->exp_pending = false;
+    s->pend_demand = false;
+    if (s->pend_count) {
+        s->pend_count = false;
+        hipLaunchKernelGGL(k_count, dim3(s->n_segs, s->pend_frusta), dim3(YH_BLOCK), 0, s->ctx->stream, s->pend);
+    }
     hipLaunchKernelGGL(k_expand, dim3(cdiv(s->pend.n_tiles, s->pend.tiles_per_wg), s->pend_frusta), dim3(YH_BLOCK), 0, s->ctx->stream, s->pend);
     HIP_TRY(s->ctx, hipGetLastError());
     return YH_OK;
@@ -1334,6 +1350,8 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
         return fail(ctx, YH_ERR_UNSUPPORTED, "yh_frame: TRS scenes recompute every entity; pass YH_FRAME_ALL_DIRTY");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    if (s->exp_pending && s->pend_demand)  // nobody read the lists of a YH_FRAME_LISTS_ON_DEMAND frame: dropped unexpanded
+        s->exp_pending = s->pend_demand = s->pend_count = false;
     StaticLayout sl{};
     unsigned char* const sp = ctx->scratch_ptr;  // the device address of this GPU's copy, never the array's name
     if (use_static) {
@@ -1362,7 +1380,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
     a.ldirty = s->ldirty;
     a.wdirty = s->wdirty;
     a.alive = s->alive;
-    a.bcount = s->counts + YH_MAX_FRUSTA * (1 + s->bset);
+    a.bcount = s->bsets + YH_MAX_FRUSTA * s->bset;
     // visibility words and their byte counts: frames alternate between two sets (the previous frame's may still be
     // waiting for its deferred expansion, or be on their way through the collective stream)
     uint64_t* words = s->vismask;
@@ -1585,9 +1603,10 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
             x.tilecnt = s->tilecnt;
             // three sets of boundary counters: this frame's, the next frame's (its launches may already be adding to
             // it when a deferred expansion runs) and the one after, which this expansion zeroes
-            x.bcount_cur = s->counts + YH_MAX_FRUSTA * (1 + s->bset);
-            x.bcount_next = s->counts + YH_MAX_FRUSTA * (1 + (s->bset + 2u) % 3u);
-            s->bset = (s->bset + 1u) % 3u;
+            x.bcount_cur = s->bsets + YH_MAX_FRUSTA * s->bset;
+            x.bcount_next = s->bsets + YH_MAX_FRUSTA * ((s->bset + 2u) % YH_BSETS);
+            s->bset = (s->bset + 1u) % YH_BSETS;
+            if (s->bzero_ahead) --s->bzero_ahead;  // (the window of bulk-zeroed sets ends one frame nearer)
         }
         for (uint32_t f = 0; f < YH_MAX_FRUSTA; ++f) x.draw[f] = s->draw[f];
         x.draw_cap = s->draw_cap;
@@ -1598,6 +1617,26 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
         x.id_base = s->desc.id_base;
         x.self_count = (s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES && s->tile_words <= 64u);
         x.tiles_per_wg = expand_tiles_per_wg(s, n_frusta);
+        // Lists on demand (frames whose words go to the gather, which expands this GPU's part along with the others'):
+        // neither tile bases nor lists unless somebody asks before the next frame; what k_expand does on the side - the
+        // boundary counters of the frame after next start at zero - is done by a one-wave kernel.
+        const bool on_demand = !use_static && (flags & YH_FRAME_ASYNC) && (flags & YH_FRAME_LISTS_ON_DEMAND) &&
+                               !(ktiming && s->timing_only == -1);
+        if (on_demand) {
+            if (s->bzero_ahead == 0) {  // sets k + 2 .. k + 33 (s->bset is already k + 1): last used 31..62 frames ago
+                hipLaunchKernelGGL(k_zero_sets, dim3(1), dim3(YH_BLOCK), 0, st, s->bsets, (s->bset + 1u) % YH_BSETS,
+                                   (uint32_t)YH_BZERO_AHEAD, (uint32_t)YH_BSETS);
+                HIP_TRY(ctx, hipGetLastError());
+                ++launches;
+                s->bzero_ahead = YH_BZERO_AHEAD;
+            }
+            s->pend = x;
+            s->pend_frusta = n_frusta;
+            s->exp_pending = true;
+            s->pend_demand = true;
+            s->pend_count = !x.self_count;
+            goto cull_done;
+        }
         if (int rc = time_begin(YH_MAX_LEVELS - 1)) return rc;
         if (!x.self_count) {
             hipLaunchKernelGGL(k_count, dim3(s->n_segs, n_frusta), dim3(YH_BLOCK), 0, st, x);
@@ -1624,6 +1663,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
         }
         if (int rc = time_end()) return rc;
     }
+cull_done:
     if (frame_events) HIP_TRY(ctx, hipEventRecord(s->ev1, st));
     s->frame_timed = frame_events;
     s->frame_pending = true;
