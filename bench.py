@@ -367,7 +367,7 @@ def run_workload(job, name, steps, warmup, headline, entities=0):
             job.comm_err = err
         collective = ("rccl (library, collective stream): one ncclAllGather of the frame's VISIBILITY WORDS (n/8 bytes per "
                       "frustum and rank, not index lists: 20-32x fewer bytes over xGMI), every rank expands all ranks' words "
-                      "into the gathered draw lists itself; runs beside the next frames" if job.use_lib_comm
+                      "into the gathered draw lists itself (its own part included: the frames pass YH_FRAME_LISTS_ON_DEMAND); runs beside the next frames" if job.use_lib_comm
                       else f"torch.distributed nccl stand-by (library communicator failed: {job.comm_err[:120]})")
 
     def step():
