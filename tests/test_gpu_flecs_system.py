@@ -168,6 +168,48 @@ def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, le
             assert np.array_equal(np.sort(vis[f]), idx[np.flatnonzero(exp_vis[f])]), f"frame {fi} frustum {f}: visible set"
 
 
+def test_long_edit_lists_are_gathered_by_helper_threads(oracle, tmp_path):
+    """Frames with tens of thousands of onSet calls: the rows are collected from their tables by several threads, each
+    with a range of the list (2048 rows per thread at least); entities set twice in a frame, in the same range or in
+    two, travel once with their last value.  Against the CPU systems, row for row."""
+    n, levels = 60_000, 6
+    rng = np.random.default_rng(77)
+    lo = oracle.synth_level_offsets(n, levels)
+    par = oracle.synth_parents(lo)
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo[1])))
+    bounds = oracle.synth_aabb(n)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+
+    def rnd_m(scale=5.0):
+        return oracle.compose(rng.uniform(-scale, scale, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+
+    many = rng.permutation(n)[:14_000]
+    again = np.concatenate([many[:1500], many[-1500:]])  # set twice: near the first set, and a whole list away from it
+    frames = [[], [],
+              [(int(e), 0, rnd_m()) for e in many] + [(int(e), 0, rnd_m()) for e in again],
+              [(int(e), 1, rnd_m(50.0)) for e in rng.permutation(n)[:9_000]],
+              [(int(e), int(k), rnd_m()) for e, k in zip(rng.permutation(n)[:20_000], rng.integers(0, 2, 20_000))],
+              []]
+    scene, out_c, out_g = tmp_path / "scene.bin", tmp_path / "cpu.bin", tmp_path / "gpu.bin"
+    write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
+    subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
+    env["YFH_THREADS"] = "6"
+    subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
+    cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
+    gpu = read_out(out_g, n, len(frames), 1, oracle.T68, gpu=True)
+    for fi, ((cw, cl, _, rows, _), (gw, gl, _reb, g_rows, vis)) in enumerate(zip(cpu, gpu)):
+        with np.errstate(all="ignore"):
+            assert np.array_equal(gw["m"], cw["m"], equal_nan=True), f"frame {fi}: world matrices {vis[-1]}"
+            assert np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi}: local matrices {vis[-1]}"
+        assert np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"]), f"frame {fi}: dirty bytes"
+        assert g_rows == rows == n
+        if fi >= 1:
+            assert vis[-1][0] == len({e for e, _k, _m in frames[fi]}), f"frame {fi}: every edited entity travels once: {vis[-1]}"
+        exp_vis, _ = oracle.cull(np.ascontiguousarray(cw), bounds, planes)
+        assert np.array_equal(np.sort(vis[0]), np.flatnonzero(exp_vis[0])), f"frame {fi}: visible set"
+
+
 def test_results_can_stay_on_the_device_until_readback_is_switched_on(oracle, tmp_path):
     """setReadback(0): nothing comes back (a device consumer reads matrices and lists where they are), the device stays
     right frame after frame — visible sets of every frame, structural changes included — and the frame after readback is
