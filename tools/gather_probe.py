@@ -21,4 +21,4 @@ with Scene(ctx, n, n_levels=levels, n_frusta=1) as s:
     for _ in range(5):
         s.gather_selftest(ranks)
     g = s.gathered_counts(1, ranks)
-    print(f"n={n} levels={levels} ranks={ranks}: own list {own} entries, gathered {int(g[-1, 0])} entries")
+    print(f"n={n} levels={levels} ranks={ranks}: own list {own} entries, gathered {int(g[:, 0].sum())} entries from {ranks} ranks")
