@@ -109,7 +109,8 @@ uint64_t GpuTransformCullSystem_cleanFrames(const GpuTransformCullSystem* s);
  * WorldTransform.matrix keeps working (RenderApi.zig:1398-1402, SceneWindow.zig:334-351).  Off, for a renderer that
  * takes matrices and draw records on the device (yh_build_object_data / yh_object_data_device): nothing comes back, a
  * frame that moved every entity costs what the GPU frame costs; flecs' copies of recomputed rows go stale until
- * readback is switched on again (the next frame then brings whole columns back).  fetchWorld: one entity's current
+ * readback is switched on again (the next frame then brings whole columns back); structural changes are still patched:
+ * rows the device holds change slots there (yh_move_rows), only new entities' rows are read from flecs.  fetchWorld: one entity's current
  * world matrix from the device, whatever the mode (the gizmo reads the selected entity's: SceneWindow.zig:334-351). */
 int GpuTransformCullSystem_setReadback(GpuTransformCullSystem* s, int on);
 int GpuTransformCullSystem_fetchWorld(GpuTransformCullSystem* s, ecs_entity_t entity, float matrix[16]);
