@@ -4,8 +4,12 @@ of the library) — against yh_frame on the same scenes, through the C ABI, tole
 Two calls in a row on one GPU, the second on a smaller scene: the array keeps the first call's contents, so the
 second call checks that everything that must start at zero is cleared and that nothing stale is read.  Collected
 last (test_zz_*): the round's end runs `pytest -x`."""
+import ctypes
+
 import numpy as np
 import pytest
+
+from .test_gpu_parity import assert_same_values
 
 pytestmark = pytest.mark.gpu
 
@@ -112,3 +116,55 @@ def test_frame_static_rejects_what_does_not_fit(ctx, oracle):
         c7 = s.counts()[0][:7].copy()
         s.frame(planes[:7])
         assert np.array_equal(s.counts()[0][:7], c7) and c7[0] > 0
+
+
+def test_frame_static_frames_replayed_from_a_hip_graph(ctx, oracle):
+    """What the entry point that allocates nothing is for: yh_frame_static calls (YH_FRAME_ASYNC) captured into a
+    hipGraph on the context's stream (yh_stream) and replayed.  The replay must give the lists of the captured frames'
+    LAST frame - also after the scene's inputs were changed between two replays (the graph reads the device arrays)."""
+    from yume_amd import Scene, _lib
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    for fn in ("hipStreamBeginCapture", "hipStreamEndCapture", "hipGraphInstantiate", "hipGraphLaunch", "hipGraphExecDestroy",
+               "hipGraphDestroy"):
+        getattr(hip, fn).restype = ctypes.c_int
+    n, levels = 300_000, 6
+    lo = oracle.synth_level_offsets(n, levels)
+    par = oracle.synth_parents(lo)
+    trs = oracle.synth_trs(n, int(lo[1]))
+    bounds = oracle.synth_aabb(n)
+    cams = [oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()[1:2]]
+    flags = _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC
+    with Scene(ctx, n, n_levels=levels, n_frusta=2) as s:
+        s.upload_hierarchy(par, lo)
+        s.upload_trs(trs)
+        s.upload_aabb(np.ascontiguousarray(bounds[:, :3].T), np.ascontiguousarray(bounds[:, 3:].T))
+        s.frame_static(np.concatenate(cams))  # (everything the call sets up lazily exists before the capture)
+        stream = ctypes.c_void_p(ctx.stream())
+        graph, gexec = ctypes.c_void_p(), ctypes.c_void_p()
+        assert hip.hipStreamBeginCapture(stream, 1) == 0  # hipStreamCaptureModeThreadLocal
+        try:
+            s.frame_static(cams[1], flags)
+            s.frame_static(np.concatenate(cams), flags)
+        finally:
+            rc = hip.hipStreamEndCapture(stream, ctypes.byref(graph))
+        assert rc == 0 and graph.value
+        assert hip.hipGraphInstantiate(ctypes.byref(gexec), graph, None, None, ctypes.c_ulonglong(0)) == 0
+        try:
+            for rnd in range(3):
+                if rnd:  # other inputs under the same graph
+                    trs = trs.copy()
+                    trs[0] += np.float32(3.0 * rnd)
+                    s.upload_trs(trs)
+                assert hip.hipGraphLaunch(gexec, stream) == 0
+                ctx.wait()
+                exp_w = oracle.frame_trs(trs, par, lo, n_threads=8)
+                vis, bnd = oracle.cull(exp_w, bounds, np.concatenate(cams), n_threads=8)
+                counts, bcounts = s.counts()
+                for f in range(2):
+                    assert counts[f] == np.count_nonzero(vis[f]) and bcounts[f] == np.count_nonzero(bnd[f]), (rnd, f)
+                    assert np.array_equal(s.draw_list(f), np.flatnonzero(vis[f]).astype(np.uint32)), (rnd, f)
+                assert_same_values(s.world_soa(), exp_w["m"].T, f"world, replay {rnd}")
+        finally:
+            hip.hipGraphExecDestroy(gexec)
+            hip.hipGraphDestroy(graph)
