@@ -1218,17 +1218,22 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_hist(BucketArgs a) {
     for (uint32_t m = threadIdx.x; m < a.n_meshes; m += YH_BLOCK) a.hist[(uint64_t)m * YH_BUCKET_SLICES + blockIdx.x] = h[m];
 }
 
-// Inclusive scan of one value per thread over the workgroup (256 threads), through LDS.
+// Inclusive scan of one value per thread over the workgroup (256 threads): inside each wave by lane shuffles, the four
+// wave totals through LDS (two barriers instead of the seventeen of a scan that steps through LDS; ends with a barrier).
 __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t* part) {
-    part[threadIdx.x] = v;
-    __syncthreads();
-    for (uint32_t d = 1; d < YH_BLOCK; d <<= 1) {
-        const uint32_t t = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += t;
-        __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)inc, o);
+        if (lane >= o) inc += u;
     }
-    return part[threadIdx.x];
+    if (lane == 63u) part[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += part[w];
+    __syncthreads();  // (part is the caller's again)
+    return before + inc;
 }
 
 // One workgroup per mesh: exclusive scan of the row's YH_BUCKET_SLICES counts (16 per thread), total to totals[m].
