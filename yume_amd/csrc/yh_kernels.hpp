@@ -1283,14 +1283,35 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
     for (uint32_t m = tid; m < a.n_meshes; m += YH_BLOCK) base[m] = a.starts[m] + a.hist[(uint64_t)m * YH_BUCKET_SLICES + blockIdx.x];
     uint64_t lo, hi;
     bucket_slice(a, blockIdx.x, lo, hi);
+    // Two-stage software pipeline over the slice's tiles: while tile k is sorted and written, the rows and mesh ids of
+    // tile k + 1 are in flight (their list entries were loaded during tile k - 1) and so are the list entries of tile
+    // k + 2 - plain loads survive the barriers below.  Without it every tile waited for a dependent chain of three
+    // gathers (list entry -> mesh id, matrix row) before its first barrier.
+    uint32_t id_c = lo + tid < hi ? a.list[lo + tid] : a.id_base;
+    uint32_t id_n = lo + YH_BLOCK + tid < hi ? a.list[lo + YH_BLOCK + tid] : a.id_base;
+    uint32_t m_c = lo + tid < hi ? a.mesh_id[id_c - a.id_base] : 0xFFFFFFFFu;
+    float w_c[16];
+    {
+        const uint64_t off = eoff<16>(id_c - a.id_base);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w_c[q] = lde(a.world, off, q);
+    }
     for (uint64_t i0 = lo; i0 < hi; i0 += YH_BLOCK) {  // uniform trip count for the workgroup
         const uint32_t n_tile = (uint32_t)((hi - i0 < YH_BLOCK) ? (hi - i0) : YH_BLOCK);
+        const bool next_active = i0 + YH_BLOCK + tid < hi;
+        const uint32_t m_n = next_active ? a.mesh_id[id_n - a.id_base] : 0xFFFFFFFFu;
+        float w_n[16];
+        {
+            const uint64_t off = eoff<16>(id_n - a.id_base);  // (an inactive lane re-reads entity 0's row: in bounds)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) w_n[q] = lde(a.world, off, q);
+        }
+        const uint32_t id_nn = i0 + 2 * YH_BLOCK + tid < hi ? a.list[i0 + 2 * YH_BLOCK + tid] : a.id_base;
         for (uint32_t m = tid; m < a.n_meshes; m += YH_BLOCK) wcnt[0][m] = wcnt[1][m] = wcnt[2][m] = wcnt[3][m] = 0;
         __syncthreads();
         const bool active = tid < n_tile;
-        const uint32_t id = active ? a.list[i0 + tid] : 0u;
-        const uint32_t e = id - a.id_base;
-        const uint32_t m = active ? a.mesh_id[e] : 0xFFFFFFFFu;
+        const uint32_t id = id_c;
+        const uint32_t m = active ? m_c : 0xFFFFFFFFu;
         // rank among the wave's entries of the same mesh (entries are in list order lane by lane, wave by wave)
         uint32_t rank = 0;
         uint64_t todo = __ballot(active);
@@ -1301,12 +1322,6 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
             if (m == lm) rank = lane_rank(same);
             if ((int)lane == leader) wcnt[wave][lm] = (uint32_t)__popcll(same);
             todo &= ~same;
-        }
-        float w[16];
-        if (active) {
-            const uint64_t off = eoff<16>(e);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) w[q] = lde(a.world, off, q);
         }
         __syncthreads();
         // per mesh: counts of the four waves -> exclusive wave offsets, tile total -> tile-local start by a scan
@@ -1329,7 +1344,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
             s_id[ls] = id;
             s_vc[ls] = a.vcount ? a.vcount[m] : 0u;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) rows[ls * 17 + q] = __float_as_uint(w[q]);
+            for (int q = 0; q < 16; ++q) rows[ls * 17 + q] = __float_as_uint(w_c[q]);
         }
         __syncthreads();
         if (tid < a.n_meshes) base[tid] += tile_cnt;
@@ -1340,6 +1355,11 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
         }
         for (uint32_t i = tid; i < n_tile * 16u; i += YH_BLOCK) a.obj[(uint64_t)s_pos[i >> 4] * 16 + (i & 15u)] = rows[(i >> 4) * 17 + (i & 15u)];
         __syncthreads();
+        id_c = id_n;
+        id_n = id_nn;
+        m_c = m_n;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w_c[q] = w_n[q];
     }
 }
 
