@@ -258,7 +258,7 @@ def test_results_can_stay_on_the_device_until_readback_is_switched_on(oracle, tm
             assert down == 0 or structural or fi == 0, f"frame {fi}: rows came back although readback is off"
         else:  # the last frame ran with readback on: whole columns came home
             # (both columns whole: the rows and the spare slots every level ends in)
-            assert 2 * g_rows <= down <= 2 * (g_rows + g_rows // 8 + 64 * levels)
+            assert 2 * g_rows <= down <= 2 * (g_rows + g_rows // 8 + 1024 * levels)
             with np.errstate(all="ignore"):
                 assert np.array_equal(gw["m"], cw["m"], equal_nan=True) and np.array_equal(gl["m"], cl["m"], equal_nan=True)
             assert np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"])
@@ -304,7 +304,7 @@ def test_the_system_reads_cameras_and_mesh_bounds_from_the_ecs(oracle, tmp_path)
     subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
     cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
     gpu = read_out(out_g, n, len(frames), 2, oracle.T68, gpu=True)
-    rebuilds_before = 0
+    rebuilds_before = patches_before = 0
     for fi, ((cw, cl, _, _rows, _), (gw, gl, rebuilds, _g_rows, vis)) in enumerate(zip(cpu, gpu)):
         for e, kind, m in frames[fi]:
             if kind == 4:
@@ -319,9 +319,11 @@ def test_the_system_reads_cameras_and_mesh_bounds_from_the_ecs(oracle, tmp_path)
         for f in range(2):
             assert np.array_equal(np.sort(vis[f]), np.flatnonzero(exp_vis[f])), f"frame {fi} frustum {f}: visible set"
             assert vis[f].size > 0
-        # a Mesh set on an entity that has one moves no row (no rebuild); a first Mesh is an archetype move (rebuild)
-        assert rebuilds == rebuilds_before + (1 if fi in (0, 4) else 0), f"frame {fi}: {rebuilds} rebuilds"
-        rebuilds_before = rebuilds
+        # a Mesh set on an entity that has one moves no row (nothing structural); a first Mesh is an archetype move: the
+        # rows of forty tables move to spare slots (a patch, mesh ids included) - or, spare slots lacking, a rebuild
+        patches = vis[-1][4]
+        assert rebuilds - rebuilds_before + patches - patches_before == (1 if fi in (0, 4) else 0), f"frame {fi}: {rebuilds} rebuilds, {patches} patches"
+        rebuilds_before, patches_before = rebuilds, patches
 
 
 @pytest.mark.parametrize("seed,ecs_inputs,stale_from",  # more seeds: YH_STRUCT_SEEDS=40
@@ -337,7 +339,7 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
     are compared again after the last frame has brought everything home, the visible sets every frame."""
     rng = np.random.default_rng(1000 + seed)
     n_frames = int(os.environ.get("YH_STRUCT_FRAMES", "26"))  # a soak: YH_STRUCT_FRAMES=200
-    n0, levels, extra = 20_000, 6, 1500 * max(1, n_frames // 26)
+    n0, levels, extra = 20_000, 6, 6000 * max(1, n_frames // 26)
     n = n0 + extra
     lo0 = oracle.synth_level_offsets(n0, levels)
     par0 = oracle.synth_parents(lo0)
@@ -435,9 +437,9 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
                 for x in subtree(e):
                     alive.discard(x)
                 break
-        elif next_new + 400 <= n:  # a burst of creations under ONE parent: more than the level's 64 spare slots may hold
+        elif next_new + 1500 <= n:  # a burst of creations under ONE parent: more than the 1024 spare slots of a small level hold
             p = int(rng.choice([x for x in pool if depth[int(x)] + 1 < levels]))
-            for _ in range(int(rng.integers(100, 400))):
+            for _ in range(int(rng.integers(1100, 1500))):
                 e = next_new
                 next_new += 1
                 edits.append((e, 6, reparent_arg(p)))

@@ -37,6 +37,7 @@
 #define ROW 68u
 #define MAX_THREADS 32
 #define MESH_TABLE_MAX 65536u /* distinct meshes (+ entities with bounds of their own) a mesh-table scene can hold */
+#define SPARE_MIN 1024u /* spare slots every level gets at least (a pasted subtree, a burst of spawns) */
 #define ROWS_PER_THREAD_MIN 2048u /* below this many changed rows per helper a thread costs more than it saves */
 
 typedef struct Batch {
@@ -370,8 +371,8 @@ static int rebuild(GpuTransformCullSystem* s) {
     uint32_t* parent_batch = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
     uint32_t* parent_row = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1)); /* walk row of the parent */
     uint32_t* key = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
-    /* (slots = rows + the spare slots of every level: at most an eighth more, and 64 per level) */
-    uint32_t* parent_index = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n + n / 8 + 64u * (YH_MAX_LEVELS + 1)));
+    /* (slots = rows + the spare slots of every level: at most an eighth more, and SPARE_MIN per level) */
+    uint32_t* parent_index = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n + n / 8 + SPARE_MIN * (YH_MAX_LEVELS + 1)));
     uint32_t* stack = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
     KeyedBatch* keyed = (KeyedBatch*)malloc(sizeof(KeyedBatch) * (nb ? nb : 1));
     uint32_t level_offsets[YH_MAX_LEVELS + 1];
@@ -451,7 +452,7 @@ static int rebuild(GpuTransformCullSystem* s) {
         }
         s->level_fill[lvl] = slot;
         if (spare_slots) {
-            const uint32_t rows = slot - level_offsets[lvl], spare = rows / 8u > 64u ? rows / 8u : 64u;
+            const uint32_t rows = slot - level_offsets[lvl], spare = rows / 8u > SPARE_MIN ? rows / 8u : SPARE_MIN;
             /* a dead slot is computed like any other: it needs a parent inside the level before its own */
             for (uint32_t r = 0; r < spare; ++r) parent_index[slot + r] = lvl == 0 ? YH_NO_PARENT : level_offsets[lvl - 1];
             slot += spare;

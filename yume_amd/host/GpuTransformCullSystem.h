@@ -79,7 +79,7 @@ int GpuTransformCullSystem_setIncremental(GpuTransformCullSystem* s, int on);
 /* Small structural changes without a rebuild (default on; incremental mode with readback only).  Entities created,
  * deleted or re-parented between frames (editor/Editor.zig:590-636, GameApp.zig:204-215) change a few tables; the
  * observers list them, and the next frame moves just their rows: every level's range of slots ends in spare slots
- * (an eighth of the level, at least 64; dead on the device: yh_scene_set_alive_range), the rows of a table that changed
+ * (an eighth of the level, at least 1024; dead on the device: yh_scene_set_alive_range), the rows of a table that changed
  * take spare slots of its level, its old slots die, children of moved rows learn the new parent slot
  * (yh_upload_parent_range); a subtree re-parented to another depth takes the batches below it along to the spare slots
  * of their new levels; the batches of tables flecs deleted (the children of a deleted parent) die without their
