@@ -676,6 +676,9 @@ def test_subtrees_moved_to_other_depths_patched_equals_rebuilt(oracle, tmp_path,
         for f in range(planes.shape[0]):
             assert np.array_equal(np.sort(pvis[f]), np.sort(rvis[f])), f"frame {fi} frustum {f}: visible set {stats}"
     assert outs["patched"][-1][4][-1][4] >= 8, f"most structural frames were meant to be patched: {outs['patched'][-1][4][-1]}"
+    # the scene is built with two empty levels below its deepest one: subtrees that end up deeper than anything did
+    # before are patched as well - nothing here rebuilds after the first frame
+    assert outs["patched"][-1][2] == 1, f"{outs['patched'][-1][2]} rebuilds"
     # subtrees that change depth while flecs' columns are stale: every row moves on the device (yh_move_rows); the
     # visible sets are the device's every frame, the columns are compared once the last frame has brought them home
     stale = outs["patched, results left on the device from frame 3"]

@@ -38,6 +38,7 @@
 #define MAX_THREADS 32
 #define MESH_TABLE_MAX 65536u /* distinct meshes (+ entities with bounds of their own) a mesh-table scene can hold */
 #define SPARE_MIN 1024u /* spare slots every level gets at least (a pasted subtree, a burst of spawns) */
+#define SPARE_LEVELS 2u /* empty levels below the deepest one: a subtree dragged under a leaf is patched, not rebuilt */
 #define ROWS_PER_THREAD_MIN 2048u /* below this many changed rows per helper a thread costs more than it saves */
 
 typedef struct Batch {
@@ -424,6 +425,8 @@ static int rebuild(GpuTransformCullSystem* s) {
     /* level by level: order the level's batches by the slot of their parent, hand out slots; with patching on every
      * level's range ends in spare slots for the tables that change later (patch()) */
     const int spare_slots = s->patching && s->incremental;
+    if (spare_slots) /* (levels nobody lives on yet: spare slots only) */
+        n_levels = n_levels + SPARE_LEVELS <= YH_MAX_LEVELS ? n_levels + SPARE_LEVELS : YH_MAX_LEVELS;
     uint32_t placed = 0, slot = 0;
     for (uint32_t lvl = 0; lvl < n_levels; ++lvl) {
         level_offsets[lvl] = slot;

@@ -70,7 +70,7 @@ uint64_t GpuTransformCullSystem_visible(GpuTransformCullSystem* s, uint32_t frus
 /* Last error code of the per-frame run (0 = ok): system callbacks cannot return one. */
 int GpuTransformCullSystem_status(const GpuTransformCullSystem* s);
 uint64_t GpuTransformCullSystem_entities(const GpuTransformCullSystem* s);
-uint32_t GpuTransformCullSystem_levels(const GpuTransformCullSystem* s);
+uint32_t GpuTransformCullSystem_levels(const GpuTransformCullSystem* s); /* levels of the device scene (the spare ones included) */
 uint64_t GpuTransformCullSystem_rebuilds(const GpuTransformCullSystem* s);
 
 /* Incremental mode (on by default): only rows whose onSet fired are uploaded, only rows the frame touched are
