@@ -25,7 +25,8 @@ for k in range(reps):
 with tempfile.TemporaryDirectory() as d:
     scene = os.path.join(d, "scene.bin")
     write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
-    for label, env in (("16 helpers (default)", {}), ("8 helpers", {"YFH_THREADS": "8"}), ("4 helpers", {"YFH_THREADS": "4"})):
+    for label, env in (("16 helpers (default)", {}), ("8 helpers", {"YFH_THREADS": "8"}), ("4 helpers", {"YFH_THREADS": "4"}),
+                       ("16 helpers, ECS inputs", {"YFH_ECS_INPUTS": "1"}), ("8 helpers, ECS inputs", {"YFH_ECS_INPUTS": "1", "YFH_THREADS": "8"})):
         e = dict({k: v for k, v in os.environ.items() if not k.startswith("YFH_")}, YFH_TIMES="1", **env)
         r = subprocess.run([GPU, scene, os.path.join(d, "out.bin")], env=e, capture_output=True, text=True, timeout=1200)
         t = [float(line.split(": ")[1].split(" ms")[0]) for line in r.stderr.splitlines() if line.startswith("frame ")]
