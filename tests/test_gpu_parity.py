@@ -240,10 +240,15 @@ def test_random_scene_shapes_plans_and_frame_sequences(ctx, oracle, seed):
     """Seeded random differential test: level counts 1..12, uneven level sizes from a few entities to ~200k (so that
     launches below and above the XCD-ordering threshold, ragged tiles and chunk-straddling level boundaries all occur),
     random launch plans, id offsets, 1..4 frusta, and a random mix of synchronous and YH_FRAME_ASYNC frames (deferred
-    expansion riding on the next frame).  World matrices, lists and boundary counts must equal the oracle's."""
+    expansion riding on the next frame; lists on demand).  World matrices, lists and boundary counts must equal the oracle's."""
     from yume_amd import _lib
 
     rng = np.random.default_rng(1000 + seed)
+    rng_flag = np.random.default_rng(9000 + seed)  # (its own stream: the scenes of the seeds stay what they were)
+
+    def on_demand():  # a third of the asynchronous frames leave their lists unexpanded unless read
+        return _lib.YH_FRAME_LISTS_ON_DEMAND if rng_flag.random() < 0.33 else 0
+
     n_levels = int(rng.integers(1, 13))
     sizes = [int(rng.choice([rng.integers(1, 70), rng.integers(70, 5000), rng.integers(5000, 200_000)], p=[0.2, 0.4, 0.4]))
              for _ in range(n_levels)]
@@ -269,8 +274,8 @@ def test_random_scene_shapes_plans_and_frame_sequences(ctx, oracle, seed):
                 s.set_plan([])
             nf = int(rng.integers(1, 5))
             for _ in range(int(rng.integers(0, 4))):  # frames that are overwritten before anyone looks
-                s.frame(cams[: int(rng.integers(1, 5))], _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC)
-            s.frame(cams[:nf], _lib.YH_FRAME_ALL_DIRTY | (_lib.YH_FRAME_ASYNC if rng.random() < 0.7 else 0))
+                s.frame(cams[: int(rng.integers(1, 5))], _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC | on_demand())
+            s.frame(cams[:nf], _lib.YH_FRAME_ALL_DIRTY | ((_lib.YH_FRAME_ASYNC | on_demand()) if rng.random() < 0.7 else 0))
             counts, bcounts = s.counts()
             for f in range(nf):
                 exp_set = np.flatnonzero(vis_all[f]).astype(np.uint32) + np.uint32(base)
