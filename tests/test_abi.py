@@ -207,3 +207,21 @@ def test_integration_patch_applies_to_the_reference_tree(tmp_path):
     assert "GpuTransformCullSystem = @import" in open(tmp_path / "engine/ecs.zig").read()
     ed = open(tmp_path / "editor/Editor.zig").read()
     assert "GpuTransformCullSystem.registerTo(ctx.world)" in ed and "PostTransformSystem.registerTo" not in ed
+
+
+def test_python_constants_equal_the_headers_defines():
+    """Flags, error codes and enums that yume_amd/_lib.py spells out again must be the header's values."""
+    import re
+
+    from yume_amd import _lib
+
+    text = open(os.path.join(ROOT, "include", "yume_hip.h")).read()
+    defines = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^#define\s+(YH_[A-Z0-9_]+)\s+\(?(-?(?:0x[0-9a-fA-F]+|\d+))u?\)?\s*(?:/\*.*)?$", text, re.M)}
+    enums = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"\b(YH_[A-Z0-9_]+)\s*=\s*(-?(?:0x[0-9a-fA-F]+|\d+))", text)}
+    known = dict(defines, **enums)
+    checked = 0
+    for name in dir(_lib):
+        if name.startswith("YH_") and isinstance(getattr(_lib, name), int) and name in known:
+            assert getattr(_lib, name) == known[name], name
+            checked += 1
+    assert checked >= 12 and _lib.YH_FRAME_LISTS_ON_DEMAND == defines["YH_FRAME_LISTS_ON_DEMAND"]
