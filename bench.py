@@ -411,8 +411,8 @@ def run_workload(job, name, steps, warmup, headline, entities=0):
     # (hipExtLaunchKernelGGL on the library's stream: the dispatch's own start/end timestamps, the ones rocprofv3's
     # kernel trace reports; nothing is added to the stream) — all transform launches of a sampled frame, not just the
     # dominant one: a launch whose predecessor is not instrumented reads ~3 us long.  An instrumented frame costs the
-    # stream ~20 us: 25 samples at most for short frames, every 4th frame for frames of milliseconds.
-    period = max(4, min(64, steps // 25))
+    # stream ~20 us: a dozen samples or more, every 64th frame at most for short frames, every 4th for frames of milliseconds.
+    period = max(4, min(64, steps // 12))
     if not args.no_kernel_events:
         scene.set_kernel_timing(-1, period)
     elapsed = timed(steps)
