@@ -422,7 +422,7 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
     alloc((void**)&s->counts, s->vis_bytes);
     alloc((void**)&s->bsets, (uint64_t)YH_BSETS * YH_MAX_FRUSTA * 4);
     if (e == hipSuccess) {
-        s->tilecnt = s->counts + 4 * YH_MAX_FRUSTA;  // [0,8) totals, [8,16) and [16,24) boundary counters (two parities)
+        s->tilecnt = s->counts + 4 * YH_MAX_FRUSTA;  // [0,8) totals ([8,32): unused since the boundary counters moved to s->bsets)
         s->vismask = (uint64_t*)(s->tilecnt + tile_words);
         // byte popcounts of the words, rows of cnt_stride bytes read 16 at a time: 16-byte aligned start
         s->viscnt = (uint8_t*)(((uintptr_t)(s->vismask + F_alloc * s->n_chunks) + 15) & ~(uintptr_t)15);
@@ -1601,8 +1601,8 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
             s->last_mparity = s->mparity;
             if (s->mask_alt) s->mparity = (s->mparity + 1u) % YH_MASK_SETS;
             x.tilecnt = s->tilecnt;
-            // three sets of boundary counters: this frame's, the next frame's (its launches may already be adding to
-            // it when a deferred expansion runs) and the one after, which this expansion zeroes
+            // boundary counters (a ring of YH_BSETS sets): this frame's, the next frame's (its launches may already be
+            // adding to it when a deferred expansion runs) and the one after, which this expansion zeroes
             x.bcount_cur = s->bsets + YH_MAX_FRUSTA * s->bset;
             x.bcount_next = s->bsets + YH_MAX_FRUSTA * ((s->bset + 2u) % YH_BSETS);
             s->bset = (s->bset + 1u) % YH_BSETS;
