@@ -1,4 +1,4 @@
-"""Frame time of the literal-rule path (Mat4 columns, k_level_mat4 + dirty sweep): python tools/mat4_bench.py [n] [levels]"""
+"""Frame time of the literal-rule path (Mat4 columns, k_level_mat4 + dirty sweep): python tools/mat4_bench.py [n] [levels] [all|dirty|clean]"""
 import sys
 import time
 
@@ -40,6 +40,12 @@ def timed(flags, frames=200):
     return (time.perf_counter() - t0) / frames * 1e6
 
 
+mode = sys.argv[3] if len(sys.argv) > 3 else "all"  # "dirty" / "clean": one kind of frame only, change tracking on (profiling runs)
+if mode != "all":
+    s.track_changes(True)
+    us = timed(_lib.YH_FRAME_ALL_DIRTY if mode == "dirty" else 0, 100)
+    print(f"n={n} L={levels} change tracking on, {'every row' if mode == 'dirty' else 'nothing'} dirty: {us:8.1f} us/frame, kernels {s.group_kernel_names()}")
+    sys.exit(0)
 for track in (False, True):
     s.track_changes(track)
     a = timed(_lib.YH_FRAME_ALL_DIRTY)
