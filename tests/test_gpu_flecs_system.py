@@ -339,7 +339,7 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
     are compared again after the last frame has brought everything home, the visible sets every frame."""
     rng = np.random.default_rng(1000 + seed)
     n_frames = int(os.environ.get("YH_STRUCT_FRAMES", "26"))  # a soak: YH_STRUCT_FRAMES=200
-    n0, levels, extra = 20_000, 6, 6000 * max(1, n_frames // 26)
+    n0, levels, extra = int(os.environ.get("YH_STRUCT_N", "20000")), 6, 6000 * max(1, n_frames // 26)  # a larger world: YH_STRUCT_N=200000
     n = n0 + extra
     lo0 = oracle.synth_level_offsets(n0, levels)
     par0 = oracle.synth_parents(lo0)
