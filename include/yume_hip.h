@@ -320,6 +320,21 @@ void yh_look_at(const float eye[3], const float at[3], const float up[3], float 
  * orthographic: rot in radians, the engine's fixed +-10 box, depth 0..200.  Feed the result to yh_extract_planes. */
 void yh_camera_view_projection(int orthographic, const float pos[3], const float rot[3], float aspect, float fovy_rad,
                                float near_z, float far_z, float view_projection_out[16]);
+/* The whole of Camera.updateMatrices (camera.zig:161-166): view and projection too (either may be NULL). */
+void yh_camera_update_matrices(int orthographic, const float pos[3], const float rot[3], float aspect, float fovy_rad,
+                               float near_z, float far_z, float view_out[16], float projection_out[16],
+                               float view_projection_out[16]);
+/* The per-camera update the engine runs before drawing with a Camera entity (editor/windows/GameWindow.zig:160-161;
+ * SURVEY 8f N4 "camera matrix pipeline"): world.decompose() -> rotation.toEuler() -> updateMatrices.
+ * yh_mat4_decompose: `matrix.decompose() catch Decomposed.IDENTITY` of one matrix (components/transform.zig:68-70,
+ * math3d.zig:828-981), t.xyz / q.xyzw / s.xyz; returns 0 where IDENTITY was substituted, else 1.
+ * yh_quat_to_euler: Quat.toEuler (math3d.zig:418-442), degrees; atan2 / asin are the host libm's ("parity unpinned":
+ * Zig's own routines are not in this image).  yh_camera_update_from_world chains the three; returns what
+ * yh_mat4_decompose does.                                                                                       */
+int yh_mat4_decompose(const float m[16], float t[3], float q[4], float s[3]);
+void yh_quat_to_euler(const float q[4], float euler_deg[3]);
+int yh_camera_update_from_world(int orthographic, const float world[16], float aspect, float fovy_rad, float near_z,
+                                float far_z, float view_out[16], float projection_out[16], float view_projection_out[16]);
 
 /* ---- synthetic scenes (measurement harness) ---------------------------------------------- */
 typedef struct yh_synth_desc {

@@ -30,6 +30,7 @@
  *              kind 6: create entity `entity` - one whose parent[] entry is 0xFFFFFFFE, i.e. not created at start - as
  *              a child of entity index bits(m[0]), with its local matrix (and bounds) from the scene's arrays
  *              (GameApp.zig:204-215: new(), setParent, set LocalTransform)
+ *              kind 7: world.enable(entity, bits(m[0]) != 0) (ecs.zig:546)
  * out.bin:   per frame: world rows n x 68 B, local rows n x 68 B (all zero for deleted entities), u64 batches,
  *            u64 rows_seen, u32 up_fields_shared; GPU build + YFH2: then per frustum u32 count, u32 entity_index[count]
  *            (GPU build: batches = slot-order rebuilds so far, rows_seen = entities in the device scene), then
@@ -39,6 +40,10 @@
  *            YFH_NO_READBACK=1: rows stay on the device (setReadback(0)) until the last frame, which brings whole columns back;
  *            YFH_VALIDATE=1: do not trust the structural-change observers, compare every cached table every frame;
  *            YFH_NO_PATCH=1: setPatching(0); YFH_READBACK_OFF_FROM=k: setReadback(0) from frame k to the last but one.
+ *            YFH_CAMERA_PIPELINE="i,j" (implies YFH_ECS_INPUTS): the two Camera components sit on scene entities i and j
+ *            (camera 0 perspective 75 deg / 0.1 / 200, camera 1 orthographic) with all three matrices zero, and the system
+ *            derives this frame's matrices itself (setCameraPipeline, aspect 2); after `patches` every frame then writes
+ *            per camera f32 view[16], projection[16], view_projection[16] as the component holds them.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -201,7 +206,8 @@ int main(int argc, char** argv) {
         uint8_t vertex_buffer[32];
     } FakeMesh;
     static FakeMesh fake_meshes[3];
-    const int ecs_inputs = getenv("YFH_ECS_INPUTS") != NULL;
+    const char* cam_pipeline = getenv("YFH_CAMERA_PIPELINE");
+    const int ecs_inputs = getenv("YFH_ECS_INPUTS") != NULL || cam_pipeline != NULL;
     ecs_entity_t camera_id = 0, mesh_id = 0, cams[2] = {0, 0};
     if (ecs_inputs) {
         ecs_entity_desc_t ed = {0};
@@ -233,6 +239,19 @@ int main(int argc, char** argv) {
                 ecs_set_id(w, ent[e], mesh_id, sizeof ref, &ref);
             }
         uint8_t cam[240];
+        if (cam_pipeline) { /* cameras ON scene entities, matrices left for the system to derive */
+            unsigned ci = 0, cj = 0;
+            if (sscanf(cam_pipeline, "%u,%u", &ci, &cj) != 2 || ci >= n || cj >= n || !ent[ci] || !ent[cj]) return 2;
+            const float persp[3] = {(float)(75.0 * 3.14159265358979323846 / 180.0), 0.1f, 200.0f};
+            memset(cam, 0, sizeof cam);
+            memcpy(cam + 4, persp, sizeof persp); /* opts.data.perspective (camera.zig:28-32) */
+            cams[0] = ent[ci];
+            ecs_set_id(w, cams[0], camera_id, sizeof cam, cam);
+            memset(cam, 0, sizeof cam);
+            cam[0] = 1; /* CameraKind.orthographic */
+            cams[1] = ent[cj];
+            ecs_set_id(w, cams[1], camera_id, sizeof cam, cam);
+        } else {
         float proj[16], view[16], vp[16];
         const float eye0[3] = {0.0f, 40.0f, 150.0f}, at[3] = {0.0f, 0.0f, 0.0f}, up[3] = {0.0f, 1.0f, 0.0f};
         yh_perspective((float)(75.0 * 3.14159265358979323846 / 180.0), 2.0f, 0.1f, 200.0f, proj);
@@ -250,6 +269,7 @@ int main(int argc, char** argv) {
         memcpy(cam + 176, vp, 64);
         cams[1] = ecs_new(w);
         ecs_set_id(w, cams[1], camera_id, sizeof cam, cam);
+        }
     }
     yh_ctx* ctx = NULL;
     if (yh_init(0, &ctx) != YH_OK) {
@@ -263,6 +283,10 @@ int main(int argc, char** argv) {
         if (GpuTransformCullSystem_setCameraComponent(gpu, camera_id, 176) != YH_OK ||
             GpuTransformCullSystem_setMeshComponent(gpu, mesh_id, 32, 16) != YH_OK)
             return 3;
+        if (cam_pipeline) { /* @offsetOf of opts.kind, opts.data, view, projection, view_projection (camera.zig:42-66) */
+            const GpuCameraLayout layout = {0, 4, 48, 112, 176};
+            if (GpuTransformCullSystem_setCameraPipeline(gpu, &layout, 2.0f) != YH_OK) return 3;
+        }
         n_frusta = 2;
     } else if (v2) {
         for (uint32_t e = 0; e < n; ++e)
@@ -324,6 +348,12 @@ int main(int argc, char** argv) {
                 uint32_t np;
                 memcpy(&np, m, 4);
                 ecs_add_id(w, target, ecs_pair(EcsChildOf, np == 0xFFFFFFFFu ? root : ent[np]));
+                continue;
+            }
+            if (kind == 7) { /* world.enable(entity, bits(m[0]) != 0) (ecs.zig:546): the Disabled tag comes or goes */
+                uint32_t on;
+                memcpy(&on, m, 4);
+                ecs_enable(w, target, on != 0);
                 continue;
             }
             if (kind == 4 || kind == 5) { /* cull inputs held by the ECS: GPU build with YFH_ECS_INPUTS only */
@@ -427,6 +457,13 @@ int main(int argc, char** argv) {
         fwrite(walk_stats, 8, 2, fout);
         const uint64_t patches = GpuTransformCullSystem_patches(gpu);
         fwrite(&patches, 8, 1, fout);
+        if (cam_pipeline)
+            for (int k = 0; k < 2; ++k) {
+                const uint8_t* cam = (const uint8_t*)ecs_get_id(w, cams[k], camera_id);
+                if (!cam) return 5;
+                fwrite(cam + 48, 64, 3, fout);
+                if (GpuTransformCullSystem_frustumCamera(gpu, (uint32_t)k) != cams[k]) return 6; /* query order = creation order here */
+            }
 #endif
     }
 #ifdef USE_GPU_SYSTEM

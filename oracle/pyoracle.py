@@ -27,6 +27,8 @@ def lib():
         L.yo_synth_raw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64]
         L.yo_frame_aos68.restype = C.c_size_t
         L.yo_inverse.restype = C.c_int
+        L.yo_decompose.restype = C.c_int
+        L.yo_camera_update_from_world.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -100,6 +102,30 @@ def camera_view_projection(orthographic, pos, rot, aspect=2.0, fovy_rad=1.308996
     lib().yo_camera_view_projection(int(orthographic), _p(pos), _p(rot), C.c_float(aspect), C.c_float(fovy_rad),
                                     C.c_float(near), C.c_float(far), _p(out))
     return out
+
+
+def quat_to_euler(q):
+    q = _f32(q).reshape(4)
+    out = np.empty(3, np.float32)
+    lib().yo_quat_to_euler(_p(q), _p(out))
+    return out
+
+
+def decompose(m):
+    """Mat4.decompose of one matrix: (t, q xyzw, s, ok); the outputs are undefined where ok is False."""
+    m = _f32(m).reshape(16)
+    t, q, s = np.zeros(3, np.float32), np.zeros(4, np.float32), np.zeros(3, np.float32)
+    ok = lib().yo_decompose(_p(m), _p(t), _p(q), _p(s))
+    return t, q, s, bool(ok)
+
+
+def camera_update_from_world(orthographic, world, aspect=2.0, fovy_rad=1.3089969, near=0.1, far=200.0):
+    """GameWindow.zig:160-161: (view, projection, view_projection, decompose succeeded)."""
+    world = _f32(world).reshape(16)
+    view, proj, vp = (np.empty(16, np.float32) for _ in range(3))
+    ok = lib().yo_camera_update_from_world(int(orthographic), _p(world), C.c_float(aspect), C.c_float(fovy_rad),
+                                           C.c_float(near), C.c_float(far), _p(view), _p(proj), _p(vp))
+    return view, proj, vp, bool(ok)
 
 
 def extract_planes(vp):

@@ -225,14 +225,14 @@ void yo_rotation(const float axis_in[3], float angle_rad, yo_mat4* out) {
     out->v[12] = 0.0f; out->v[13] = 0.0f; out->v[14] = 0.0f; out->v[15] = 1.0f;
 }
 
-/* engine/components/camera.zig:253-302: view = Rx * Ry * Rz * T(-pos); perspective: angles in degrees, projection
- * with unnamed[1][1] negated (Vulkan Y flip); orthographic: angles taken as radians, fixed +-10 box, depth 0..200;
- * view_projection = projection * view. */
-void yo_camera_view_projection(int orthographic, const float pos[3], const float rot[3], float aspect, float fovy_rad,
-                               float near_z, float far_z, yo_mat4* out) {
+/* engine/components/camera.zig:161-166 (updateMatrices) -> :253-302: view = Rx * Ry * Rz * T(-pos); perspective:
+ * angles in degrees, projection with unnamed[1][1] negated (Vulkan Y flip); orthographic: angles taken as they come
+ * (radians), fixed +-10 box, depth 0..200; view_projection = projection * view. */
+void yo_camera_update_matrices(int orthographic, const float pos[3], const float rot[3], float aspect, float fovy_rad,
+                               float near_z, float far_z, yo_mat4* view, yo_mat4* projection, yo_mat4* view_projection) {
     const float rad_per_deg = 0.017453292519943295769f;
     static const float ax[3] = {1.0f, 0.0f, 0.0f}, ay[3] = {0.0f, 1.0f, 0.0f}, az[3] = {0.0f, 0.0f, 1.0f};
-    yo_mat4 rx, ry, rz, tr, a, b, view, proj;
+    yo_mat4 rx, ry, rz, tr, a, b;
     yo_rotation(ax, orthographic ? rot[0] : rot[0] * rad_per_deg, &rx);
     yo_rotation(ay, orthographic ? rot[1] : rot[1] * rad_per_deg, &ry);
     yo_rotation(az, orthographic ? rot[2] : rot[2] * rad_per_deg, &rz);
@@ -240,14 +240,57 @@ void yo_camera_view_projection(int orthographic, const float pos[3], const float
     yo_translation(g, &tr);
     yo_mul(&rx, &ry, &a);
     yo_mul(&a, &rz, &b);
-    yo_mul(&b, &tr, &view);
+    yo_mul(&b, &tr, view);
     if (orthographic) {
-        yo_orthographic(-10.0f, 10.0f, -10.0f, 10.0f, 0.0f, 200.0f, &proj);
+        yo_orthographic(-10.0f, 10.0f, -10.0f, 10.0f, 0.0f, 200.0f, projection);
     } else {
-        yo_perspective(fovy_rad, aspect, near_z, far_z, &proj);
-        proj.v[5] *= -1.0f;
+        yo_perspective(fovy_rad, aspect, near_z, far_z, projection);
+        projection->v[5] *= -1.0f;
     }
-    yo_mul(&proj, &view, out);
+    yo_mul(projection, view, view_projection);
+}
+
+void yo_camera_view_projection(int orthographic, const float pos[3], const float rot[3], float aspect, float fovy_rad,
+                               float near_z, float far_z, yo_mat4* out) {
+    yo_mat4 view, proj;
+    yo_camera_update_matrices(orthographic, pos, rot, aspect, fovy_rad, near_z, far_z, &view, &proj, out);
+}
+
+/* engine/math3d.zig:418-442 (Quat.toEuler): roll about x, pitch about y (clamped to +-90 degrees when |sinp| >= 1),
+ * yaw about z, then radians -> degrees as `mulf(180.0).divf(pi)`.  std.math.atan2 / asin are libm's here ("parity
+ * unpinned", like yo_rotation's cos / sin). */
+void yo_quat_to_euler(const float q[4], float euler_deg[3]) {
+    const float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+    const float half_pi = (float)(3.14159265358979323846 / 2.0);
+    const float pi_f = (float)3.14159265358979323846;
+    float e[3] = {0.0f, 0.0f, 0.0f};
+    const float sinr_cosp = 2.0f * (qw * qx + qy * qz);
+    const float cosr_cosp = 1.0f - 2.0f * (qx * qx + qy * qy);
+    e[0] = atan2f(sinr_cosp, cosr_cosp);
+    const float sinp = 2.0f * (qw * qy - qz * qx);
+    if (fabsf(sinp) >= 1.0f) e[1] = copysignf(half_pi, sinp);
+    else e[1] = asinf(sinp);
+    const float siny_cosp = 2.0f * (qw * qz + qx * qy);
+    const float cosy_cosp = 1.0f - 2.0f * (qy * qy + qz * qz);
+    e[2] = atan2f(siny_cosp, cosy_cosp);
+    for (int i = 0; i < 3; ++i) euler_deg[i] = (e[i] * 180.0f) / pi_f;
+}
+
+/* editor/windows/GameWindow.zig:154-178, per Camera entity: `transform.decompose()` (components/transform.zig:68-70:
+ * IDENTITY on InvalidMatrix) -> `rotation.toEuler()` -> `camera.updateMatrices(translation, euler, aspect)`.
+ * Returns what yo_decompose returns. */
+int yo_camera_update_from_world(int orthographic, const yo_mat4* world, float aspect, float fovy_rad, float near_z,
+                                float far_z, yo_mat4* view, yo_mat4* projection, yo_mat4* view_projection) {
+    float t[3], q[4], sc[3], euler[3];
+    const int ok = yo_decompose(world, t, q, sc);
+    if (!ok) { /* math3d.zig:535-539 */
+        t[0] = t[1] = t[2] = 0.0f;
+        q[0] = q[1] = q[2] = 0.0f; q[3] = 1.0f;
+        sc[0] = sc[1] = sc[2] = 1.0f;
+    }
+    yo_quat_to_euler(q, euler);
+    yo_camera_update_matrices(orthographic, t, euler, aspect, fovy_rad, near_z, far_z, view, projection, view_projection);
+    return ok;
 }
 
 /* ----------------------------------------------------------------------------------------------- systems */
@@ -344,7 +387,8 @@ void yo_compose_batch(const float* trs, size_t stride, size_t first, size_t coun
  * perspective vector it solves for is never returned, so only that branch's side effect is kept (the perspective
  * partition is cleared).  Returns 0 where the reference returns error.InvalidMatrix. */
 #define YO_EPS 1.1920928955078125e-07f
-static int eps_eql(float a, float b) { return fabsf(a - b) <= YO_EPS; }
+static int eps_eql(float a, float b) { return fabsf(a - b) <= YO_EPS; }     /* math3d.zig:1113-1115 */
+static int eps_not_eql(float a, float b) { return fabsf(a - b) > YO_EPS; }  /* math3d.zig:1117-1119: false for NaN, unlike !eps_eql */
 static float v3_len(const float v[3]) { return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 static void v3_norm_zero(float v[3]) { /* Vec3.normalized: zero vector when the length is not > 0 */
     const float l = v3_len(v);
@@ -367,7 +411,7 @@ int yo_decompose(const yo_mat4* in, float t[3], float q[4], float sc[3]) {
     const float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) +
                       m[2] * (m[4] * m[9] - m[5] * m[8]);
     if (eps_eql(det, 0.0f)) return 0;
-    if (!eps_eql(m[3], 0.0f) || !eps_eql(m[7], 0.0f) || !eps_eql(m[11], 0.0f)) {
+    if (eps_not_eql(m[3], 0.0f) || eps_not_eql(m[7], 0.0f) || eps_not_eql(m[11], 0.0f)) { /* math3d.zig:854-856 */
         m[3] = m[7] = m[11] = 0.0f;
         m[15] = 1.0f;
     }

@@ -52,6 +52,13 @@ void yo_rotation(const float axis[3], float angle_rad, yo_mat4* out);          /
 void yo_camera_view_projection(int orthographic, const float pos[3], const float rot[3], float aspect, float fovy_rad,
                                float near_z, float far_z, yo_mat4* out);       /* components/camera.zig:253-302 */
 void yo_look_at(const float eye[3], const float at[3], const float up[3], yo_mat4* out);    /* :991-1021 */
+void yo_camera_update_matrices(int orthographic, const float pos[3], const float rot[3], float aspect, float fovy_rad,
+                               float near_z, float far_z, yo_mat4* view, yo_mat4* projection,
+                               yo_mat4* view_projection);                      /* components/camera.zig:161-166, 253-302 */
+void yo_quat_to_euler(const float q[4] /* x,y,z,w */, float euler_deg[3]);     /* math3d.zig:418-442 */
+/* editor/windows/GameWindow.zig:160-161: decompose (IDENTITY on error) -> toEuler -> updateMatrices */
+int yo_camera_update_from_world(int orthographic, const yo_mat4* world, float aspect, float fovy_rad, float near_z,
+                                float far_z, yo_mat4* view, yo_mat4* projection, yo_mat4* view_projection);
 
 /* ---- systems ---- */
 /* engine/systems/TransformSyncSystem.zig:53-74 applied to one flecs table batch.  `parent` is the ONE

@@ -73,6 +73,14 @@ int main(void) {
     expect(s, "local_removed", 1);
     ecs_add_id(w, root, tag); /* the root holds a WorldTransform only: its table is one the Up term reads */
     expect(s, "root_moved_archetype", 1);
+    /* world.enable(e, false) (ecs.zig:546) adds the Disabled tag: the row moves to a table the system's query does not
+     * match (flecs leaves disabled entities and prefabs out); enabling brings it back.  Both must be seen. */
+    ecs_enable(w, e[1], false);
+    expect(s, "entity_disabled", 1);
+    ecs_enable(w, e[1], true);
+    expect(s, "entity_enabled_again", 1);
+    ecs_add_id(w, e[1], EcsPrefab);
+    expect(s, "entity_made_a_prefab", 1);
     GpuTransformCullSystem_destroy(s);
     ecs_fini(w);
     return bad;

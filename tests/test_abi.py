@@ -85,6 +85,51 @@ def test_host_helpers_match_oracle(oracle):
             assert np.array_equal(a, oracle.camera_view_projection(ortho, pos, rot, 1.7, 1.2, 0.1, 500.0))
 
 
+def test_camera_pipeline_helpers_match_oracle_and_known_answers(oracle):
+    """GameWindow.zig:160-161 per camera: decompose -> Quat.toEuler (math3d.zig:418-442) -> updateMatrices
+    (camera.zig:161-166).  The library's host helpers against the oracle's twins, bit for bit, plus the answers the
+    reference's formulas fix without any trigonometry table: identity, the |sinp| >= 1 branch, the degrees conversion."""
+    from yume_amd import api
+
+    rng = np.random.default_rng(5)
+    for i in range(400):
+        m = oracle.compose(rng.uniform(-50, 50, 3), rng.uniform(-1, 1, 4), rng.uniform(0.3, 3, 3))
+        if i % 9 == 0:
+            m[rng.integers(0, 16)] = 0.0
+        if i % 31 == 0:
+            m[:] = 0.0  # InvalidMatrix -> Decomposed.IDENTITY (components/transform.zig:68-70)
+        t, q, s, ok = api.mat4_decompose(m)
+        ot, oq, os_, ook = oracle.decompose(m)
+        assert ok == ook
+        if ok:
+            assert np.array_equal(t, ot) and np.array_equal(q, oq, equal_nan=True) and np.array_equal(s, os_, equal_nan=True)
+        else:
+            assert np.array_equal(np.concatenate([t, q, s]), np.float32([0, 0, 0, 0, 0, 0, 1, 1, 1, 1]))
+        assert np.array_equal(api.quat_to_euler(q), oracle.quat_to_euler(q), equal_nan=True)
+        for ortho in (0, 1):
+            a = api.camera_update_from_world(ortho, m, 1.6, 1.1, 0.2, 300.0)
+            b = oracle.camera_update_from_world(ortho, m, 1.6, 1.1, 0.2, 300.0)
+            assert a[3] == b[3] == ok
+            for x, y in zip(a[:3], b[:3]):
+                assert np.array_equal(x, y, equal_nan=True)
+    assert np.array_equal(oracle.quat_to_euler([0, 0, 0, 1]), np.zeros(3, np.float32))
+    # sinp = 2 (w y - z x) = 1 exactly: the copysign(half_pi) branch, converted with mulf(180).divf(pi)
+    h = np.float32(np.sqrt(np.float32(0.5)))
+    e = oracle.quat_to_euler([0, h, 0, h])
+    if np.float32(2) * (h * h) >= 1:
+        assert e[1] == np.float32(np.float32(np.pi / 2) * np.float32(180)) / np.float32(np.pi)
+    assert oracle.quat_to_euler([0, -1, 0, 1])[1] < 0 and oracle.quat_to_euler([0, 1, 0, 1])[1] > 0  # |sinp| = 2: clamped, signed
+    assert np.allclose(oracle.quat_to_euler([np.sin(0.25), 0, 0, np.cos(0.25)]), [np.degrees(0.5), 0, 0], atol=1e-4)
+    assert np.allclose(oracle.quat_to_euler([0, 0, np.sin(-0.4), np.cos(-0.4)]), [0, 0, np.degrees(-0.8)], atol=1e-4)
+    # a camera whose world matrix is a pure translation: view = T(-pos), projection Y-flipped
+    w = oracle.compose([3, -4, 5], [0, 0, 0, 1], [1, 1, 1])
+    view, proj, vp, ok = oracle.camera_update_from_world(0, w, 2.0, 1.3, 0.1, 200.0)
+    assert ok and np.array_equal(view, oracle.compose([-3, 4, -5], [0, 0, 0, 1], [1, 1, 1]))
+    p = oracle.perspective(1.3, 2.0, 0.1, 200.0).copy()
+    p[5] *= -1
+    assert np.array_equal(proj, p) and np.array_equal(vp, oracle.mul(p, view))
+
+
 def test_camera_view_projection_properties(oracle):
     """Identities the reference's camera update implies (the trig values themselves are libm's: parity unpinned)."""
     I = oracle.identity68()["m"][0]

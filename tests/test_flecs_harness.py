@@ -114,7 +114,7 @@ def test_structural_change_observers_of_the_gpu_system_inside_real_flecs(tmp_pat
                            "-lyume_hip", f"-Wl,-rpath,{os.path.join(root, 'yume_amd')}", "-lm", "-lpthread"])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     rows = [line.split() for line in r.stdout.splitlines()]
-    assert len(rows) == 13, r.stdout + r.stderr
+    assert len(rows) == 16, r.stdout + r.stderr
     for name, want, got in rows:
         assert want == got, f"{name}: structure flag {got}, expected {want}"
     assert r.returncode == 0

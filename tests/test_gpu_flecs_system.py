@@ -42,7 +42,9 @@ def write_scene(path, lo, parent, local_m, root_m, planes, bounds, frames):
                 f.write(np.ascontiguousarray(m, np.float32).tobytes())
 
 
-def read_out(path, n, n_frames, n_frusta, T68, gpu=False):
+def read_out(path, n, n_frames, n_frusta, T68, gpu=False, n_cams=0):
+    """n_cams (YFH_CAMERA_PIPELINE runs): the frame's tuple ends in an (n_cams, 3, 16) array, the view / projection /
+    view_projection matrices the Camera components hold after the frame."""
     raw = open(path, "rb").read()
     res, pos = [], 0
     for _ in range(n_frames):
@@ -60,6 +62,11 @@ def read_out(path, n, n_frames, n_frusta, T68, gpu=False):
         if gpu:
             vis.append(struct.unpack_from("<QQQQQ", raw, pos))  # last element: (rows up, rows down, walks, skipped, patches)
             pos += 40
+        if n_cams:
+            cams = np.frombuffer(raw, np.float32, n_cams * 48, pos).reshape(n_cams, 3, 16).copy()
+            pos += n_cams * 192
+            res.append((w, l, a, b, vis, cams))
+            continue
         res.append((w, l, a, b, vis))
     assert pos == len(raw)
     return res
@@ -326,6 +333,82 @@ def test_the_system_reads_cameras_and_mesh_bounds_from_the_ecs(oracle, tmp_path)
         rebuilds_before, patches_before = rebuilds, patches
 
 
+@pytest.mark.parametrize("mode", ["incremental", "whole-columns", "no-readback"])
+def test_cameras_follow_their_transforms_in_the_same_frame(oracle, tmp_path, mode):
+    """SURVEY 8f N4, the camera matrix pipeline (editor/windows/GameWindow.zig:154-178: per Camera entity
+    transform.decompose() -> rotation.toEuler() -> camera.updateMatrices).  Two cameras sit ON scene entities deep in
+    the hierarchy - a perspective one under a node that moves every frame, an orthographic one - and the system derives
+    THIS frame's matrices from the world matrix the frame is about to write.  Per frame: the matrices the components
+    hold equal the oracle's pipeline run on the CPU systems' world row of the same frame, and the visible sets equal the
+    oracle's cull with those planes.  A system that read the stored view_projection (last frame's) fails both."""
+    n, levels = 40_000, 6
+    rng = np.random.default_rng(31)
+    lo = oracle.synth_level_offsets(n, levels)
+    par = oracle.synth_parents(lo)
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo[1])))
+    mesh_box = {0: [0, 0, 0, 0, 0, 0]}
+    for k in (1, 2, 3):
+        mesh_box[k] = [-0.5 * k, -0.25 * k - 0.5, -1.0, 0.5 * k, 0.25 * k + 0.5, 1.5]
+    bounds = np.array([mesh_box[int(k)] for k in np.arange(n) % 4], np.float32)
+    cam_e = [int(lo[4]) + 17, int(lo[3]) + 5]  # level 4 and level 3
+    chain = [cam_e[0]]
+    while par[chain[-1]] != 0xFFFFFFFF:
+        chain.append(int(par[chain[-1]]))  # the perspective camera's ancestors, parent first ... level 0 last
+
+    def rnd_m(scale=5.0):
+        return oracle.compose(rng.uniform(-scale, scale, 3), rng.uniform(-1, 1, 4), rng.uniform(0.8, 1.25, 3))
+
+    frames = [
+        [],
+        [(chain[1], 0, rnd_m())],                                  # the camera's parent moves
+        [(chain[2], 0, rnd_m()), (cam_e[1], 0, rnd_m())],          # its grandparent; the orthographic camera itself
+        [],                                                        # nothing moves: matrices must stay what they were
+        [(chain[-1], 0, rnd_m(60.0)), (chain[0], 0, rnd_m())],     # its level-0 ancestor AND its own local matrix
+        [(chain[0], 1, rnd_m(40.0))],                              # the camera's WORLD matrix is edited (reverse branch)
+        [(chain[1], 1, rnd_m(40.0)), (chain[0], 1, rnd_m(40.0))],  # parent world-edited (dirty parent wins: forward branch)
+        [(-1, 1, oracle.compose([1, 2, 3], [0, 0.7071068, 0, 0.7071068], [1, 1, 1]))],  # the scene root
+        [(chain[1], 0, np.zeros(16, np.float32))],                 # a singular ancestor: decompose fails -> IDENTITY
+        [(chain[1], 0, rnd_m())] + [(int(e), 0, rnd_m()) for e in np.unique(rng.integers(0, n, 200))],
+    ]
+    scene, out_c, out_g = tmp_path / "scene.bin", tmp_path / "cpu.bin", tmp_path / "gpu.bin"
+    write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], np.zeros((1, 24), np.float32), np.zeros((n, 6), np.float32), frames)
+    subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
+    env["YFH_CAMERA_PIPELINE"] = f"{cam_e[0]},{cam_e[1]}"
+    if mode == "whole-columns":
+        env["YFH_PLAIN"] = "1"
+    if mode == "no-readback":
+        env["YFH_READBACK_OFF_FROM"] = "2"  # frames 2 .. 8 leave their rows on the device: the replay reads them there
+    subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
+    cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
+    gpu = read_out(out_g, n, len(frames), 2, oracle.T68, gpu=True, n_cams=2)
+    fovy = np.float32(75.0 * np.pi / 180.0)
+    late = 0
+    prev_planes = None
+    for fi, ((cw, cl, _, _rows, _), (gw, gl, _reb, _g_rows, vis, cams)) in enumerate(zip(cpu, gpu)):
+        if mode != "no-readback" or fi < 2 or fi + 1 == len(frames):
+            with np.errstate(all="ignore"):
+                assert np.array_equal(gw["m"], cw["m"], equal_nan=True) and np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi}"
+        planes = []
+        for k, e in enumerate(cam_e):
+            view, proj, vp, ok = oracle.camera_update_from_world(k == 1, cw["m"][e], 2.0, fovy, 0.1, 200.0)
+            for name, got, exp in zip(("view", "projection", "view_projection"), cams[k], (view, proj, vp)):
+                assert np.array_equal(got, exp, equal_nan=True), f"frame {fi} camera {k}: {name} is not this frame's"
+            planes.append(oracle.extract_planes(vp))
+        if fi == 8:  # world = parent * 0 -> all zero: InvalidMatrix -> Decomposed.IDENTITY -> a camera at the origin
+            assert not oracle.decompose(cw["m"][cam_e[0]])[3]
+        planes = np.stack(planes).astype(np.float32).reshape(2, 24)
+        exp_vis, _ = oracle.cull(np.ascontiguousarray(cw), bounds, planes)
+        for f in range(2):
+            assert np.array_equal(np.sort(vis[f]), np.flatnonzero(exp_vis[f])), f"frame {fi} frustum {f}: visible set"
+        if prev_planes is not None:  # what a system one frame late would have listed
+            old_vis, _ = oracle.cull(np.ascontiguousarray(cw), bounds, prev_planes)
+            late += int(not np.array_equal(old_vis[0], exp_vis[0]))
+        prev_planes = planes
+        assert np.flatnonzero(exp_vis[0]).size > 0 or fi == 8
+    assert late >= 5, "the script never moved the camera: the test would not tell this frame's frusta from last frame's"
+
+
 @pytest.mark.parametrize("seed,ecs_inputs,stale_from",  # more seeds: YH_STRUCT_SEEDS=40
                          [(k, k % 4 == 3, 5 if k % 4 == 1 else 0) for k in range(int(os.environ.get("YH_STRUCT_SEEDS", "4")))])
 def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cpu_systems(oracle, tmp_path, seed, ecs_inputs,
@@ -497,6 +580,79 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
             assert np.array_equal(np.sort(vis[f]), here[np.flatnonzero(exp_vis[f])]), f"frame {fi} frustum {f}: visible set {stats}"
     assert patches >= 3 and rebuilds >= 1, f"the script was meant to exercise the patch path: {patches} patches, {rebuilds} rebuilds"
     assert not stale_from or stale_patches >= 3, f"patches on device-resident rows were meant to happen: {stale_patches}"
+
+
+@pytest.mark.parametrize("no_patch", [False, True], ids=["patched", "rebuilt"])
+def test_disabled_entities_leave_and_return_and_reallocated_columns_are_refetched(oracle, tmp_path, no_patch):
+    """world.enable(e, false) (ecs.zig:546) gives an entity the Disabled tag: its row moves to a table no query matches,
+    the CPU systems stop seeing it (its rows and dirty bytes freeze), and so must the GPU system on the patched path as
+    on the rebuilt one - never listed, never written - until it is enabled again.  Same script: fifty children are
+    created in an EXISTING table and deleted again in the same frame (the table's columns may have been reallocated
+    while its rows and their order are what they were), then an old row of that table is edited: the system has to
+    fetch the column pointers afresh (host ASan run: make -C oracle _ref/flecs_gpu_harness_asan)."""
+    n0, levels, extra = 20_000, 5, 200
+    n = n0 + extra
+    rng = np.random.default_rng(11)
+    lo0 = oracle.synth_level_offsets(n0, levels)
+    par0 = oracle.synth_parents(lo0)
+    lo = np.concatenate([lo0, [n]]).astype(np.uint32)
+    parent = np.concatenate([par0, np.full(extra, 0xFFFFFFFE, np.uint32)])
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo0[1])))
+    bounds = oracle.synth_aabb(n)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+
+    def rnd_m(scale=5.0):
+        return oracle.compose(rng.uniform(-scale, scale, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+
+    def flag(on):
+        m = np.zeros(16, np.float32)
+        m.view(np.uint32)[0] = on
+        return m
+
+    last = np.arange(int(lo0[-2]), n0)
+    off = [int(e) for e in rng.choice(last, 24, replace=False)]
+    busy_parent = int(np.bincount(par0[int(lo0[-2]):n0]).argmax())       # the parent with the most children
+    siblings = np.flatnonzero(par0 == busy_parent)
+    siblings = [int(e) for e in siblings if int(e) not in off]
+    burst = list(range(n0, n0 + 50))
+    frames = [
+        [],
+        [(e, 7, flag(0)) for e in off] + [(off[0], 0, rnd_m()), (off[1], 1, rnd_m(30.0))],   # disabled, two of them edited while disabled
+        [(int(par0[e]), 0, rnd_m()) for e in off[:6]],                                       # parents of disabled leaves move
+        [(e, 7, flag(1)) for e in off[:12]]
+        + [(e, 6, reparent_arg(busy_parent)) for e in burst] + [(e, 2, np.zeros(16, np.float32)) for e in burst]
+        + [(siblings[0], 0, rnd_m())],
+        [(siblings[1], 1, rnd_m(30.0))],
+        [(e, 7, flag(1)) for e in off[12:]] + [(off[2], 0, rnd_m())],
+        [],
+    ]
+    scene, out_c, out_g = tmp_path / "scene.bin", tmp_path / "cpu.bin", tmp_path / "gpu.bin"
+    write_scene(scene, lo, parent, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
+    subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
+    if no_patch:
+        env["YFH_NO_PATCH"] = "1"
+    subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
+    cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
+    gpu = read_out(out_g, n, len(frames), 1, oracle.T68, gpu=True)
+    enabled = np.zeros(n, bool)
+    enabled[:n0] = True
+    for fi, ((cw, cl, _, rows, _), (gw, gl, rebuilds, g_rows, vis)) in enumerate(zip(cpu, gpu)):
+        for e, kind, m in frames[fi]:
+            if kind == 7:
+                enabled[e] = bool(m.view(np.uint32)[0])
+        stats = f"(rows up, rows down, walks, skipped, patches) = {vis[-1]}, rebuilds {rebuilds}"
+        with np.errstate(all="ignore"):
+            assert np.array_equal(gw["m"], cw["m"], equal_nan=True) and np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi} {stats}"
+        assert np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"]), f"frame {fi}: dirty bytes {stats}"
+        assert g_rows == rows == enabled.sum(), f"frame {fi}: {g_rows} rows on the device, {rows} in the CPU systems, {enabled.sum()} enabled {stats}"
+        idx = np.flatnonzero(enabled)
+        exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[idx]), np.ascontiguousarray(bounds[idx]), planes)
+        assert np.array_equal(np.sort(vis[0]), idx[np.flatnonzero(exp_vis[0])]), f"frame {fi}: visible set {stats}"
+    # the rows of the two entities edited while disabled kept their dirty bytes until they came back (no system saw them)
+    assert cpu[2][0]["dirty"][off[1]] == 1 and cpu[2][1]["dirty"][off[0]] == 1
+    if not no_patch:
+        assert gpu[-1][2] == 1 and gpu[-1][4][-1][4] == 3, f"three patched frames, no rebuild: {gpu[-1][4][-1]}, rebuilds {gpu[-1][2]}"
 
 
 def test_readback_switched_off_and_on_again_after_patches(oracle, tmp_path):

@@ -147,6 +147,10 @@ SIGNATURES = {
     "yh_orthographic": (None, [C.c_float] * 6 + [_vp]),
     "yh_look_at": (None, [_vp, _vp, _vp, _vp]),
     "yh_camera_view_projection": (None, [_int, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
+    "yh_camera_update_matrices": (None, [_int, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp]),
+    "yh_mat4_decompose": (_int, [_vp, _vp, _vp, _vp]),
+    "yh_quat_to_euler": (None, [_vp, _vp]),
+    "yh_camera_update_from_world": (_int, [_int, _vp, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp]),
     "yh_scene_fill_synthetic": (_int, [_vp, C.POINTER(SynthDesc)]),
     "yh_scene_fill_synthetic_shard": (_int, [_vp, C.POINTER(SynthDesc), _vp]),
     "yh_download_trs": (_int, [_vp, _vp, _u64, _u64]),

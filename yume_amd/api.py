@@ -467,6 +467,30 @@ def camera_view_projection(orthographic, pos, rot, aspect=2.0, fovy_rad=1.308996
     return out
 
 
+def mat4_decompose(m):
+    """`matrix.decompose() catch Decomposed.IDENTITY` (components/transform.zig:68-70): (t, q xyzw, s, valid)."""
+    m = np.ascontiguousarray(m, np.float32).reshape(16)
+    t, q, s = np.empty(3, np.float32), np.empty(4, np.float32), np.empty(3, np.float32)
+    ok = L.lib().yh_mat4_decompose(_ptr(m), _ptr(t), _ptr(q), _ptr(s))
+    return t, q, s, bool(ok)
+
+
+def quat_to_euler(q):
+    """Quat.toEuler (math3d.zig:418-442): degrees."""
+    q = np.ascontiguousarray(q, np.float32).reshape(4)
+    out = np.empty(3, np.float32)
+    L.lib().yh_quat_to_euler(_ptr(q), _ptr(out))
+    return out
+
+
+def camera_update_from_world(orthographic, world, aspect=2.0, fovy_rad=1.3089969, near=0.1, far=200.0):
+    """GameWindow.zig:160-161 for one Camera entity: (view, projection, view_projection, decompose succeeded)."""
+    world = np.ascontiguousarray(world, np.float32).reshape(16)
+    view, proj, vp = (np.empty(16, np.float32) for _ in range(3))
+    ok = L.lib().yh_camera_update_from_world(int(orthographic), _ptr(world), aspect, fovy_rad, near, far, _ptr(view), _ptr(proj), _ptr(vp))
+    return view, proj, vp, bool(ok)
+
+
 def extract_planes(view_projection):
     vp = np.ascontiguousarray(view_projection, np.float32).reshape(16)
     out = np.empty(24, np.float32)

@@ -161,7 +161,8 @@ YH_HD bool m4_inverse(const M4& m, M4& out) {
 // false where the reference returns error.InvalidMatrix.  out: t.xyz, q.xyzw, s.xyz.
 YH_HD bool m4_decompose(const M4& in, float (&out)[10]) {
     const float eps = 1.1920928955078125e-07f;
-    auto eql0 = [&](float a) { return __builtin_fabsf(a - 0.0f) <= eps; };
+    auto eql0 = [&](float a) { return __builtin_fabsf(a - 0.0f) <= eps; };     // epsilonEql(a, 0), math3d.zig:1113-1115
+    auto not_eql0 = [&](float a) { return __builtin_fabsf(a - 0.0f) > eps; };  // epsilonNotEql(a, 0), :1117-1119 (false for NaN)
     auto len3 = [](const float* v) { return __builtin_sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); };
     auto dot3 = [](const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
     auto normalize3 = [&](float* v) {
@@ -189,7 +190,7 @@ YH_HD bool m4_decompose(const M4& in, float (&out)[10]) {
     m[15] = m[15] / m[15];
     const float det = m[0] * (m[5] * m[10] - m[6] * m[9]) - m[1] * (m[4] * m[10] - m[6] * m[8]) + m[2] * (m[4] * m[9] - m[5] * m[8]);
     if (eql0(det)) return false;
-    if (!eql0(m[3]) || !eql0(m[7]) || !eql0(m[11])) {
+    if (not_eql0(m[3]) || not_eql0(m[7]) || not_eql0(m[11])) {  // math3d.zig:854-856
         m[3] = m[7] = m[11] = 0.0f;
         m[15] = 1.0f;
     }

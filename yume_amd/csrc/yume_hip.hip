@@ -2022,13 +2022,15 @@ static void h_rotation(const float axis_in[3], float angle_rad, float out[16]) {
     memcpy(out, m, 64);
 }
 
-// engine/components/camera.zig:253-302: Camera.view_projection from the camera's position and Euler angles.
-extern "C" void yh_camera_view_projection(int orthographic, const float pos[3], const float rot[3], float aspect,
-                                          float fovy_rad, float near_z, float far_z, float out[16]) {
-    const float rad_per_deg = 0.017453292519943295769f;
+// engine/components/camera.zig:161-166, 253-302: Camera.updateMatrices — view, projection and view_projection from the
+// camera's position and Euler angles (updatePerspective* / updateOrthographic*, updateViewProjection).
+extern "C" void yh_camera_update_matrices(int orthographic, const float pos[3], const float rot[3], float aspect,
+                                          float fovy_rad, float near_z, float far_z, float view[16], float projection[16],
+                                          float view_projection[16]) {
+    const float rad_per_deg = 0.017453292519943295769f;  // std.math.degreesToRadians (camera.zig:261-263)
     const float ax[3] = {1.0f, 0.0f, 0.0f}, ay[3] = {0.0f, 1.0f, 0.0f}, az[3] = {0.0f, 0.0f, 1.0f};
-    float rx[16], ry[16], rz[16], tr[16], a[16], b[16], view[16], proj[16];
-    h_rotation(ax, orthographic ? rot[0] : rot[0] * rad_per_deg, rx);
+    float rx[16], ry[16], rz[16], tr[16], a[16], b[16], v[16], proj[16];
+    h_rotation(ax, orthographic ? rot[0] : rot[0] * rad_per_deg, rx);  // camera.zig:283-285 takes the angles as they come
     h_rotation(ay, orthographic ? rot[1] : rot[1] * rad_per_deg, ry);
     h_rotation(az, orthographic ? rot[2] : rot[2] * rad_per_deg, rz);
     for (int i = 0; i < 16; ++i) tr[i] = (i % 5 == 0) ? 1.0f : 0.0f;  // Mat4.translation(-pos), math3d.zig:628-635
@@ -2037,14 +2039,70 @@ extern "C" void yh_camera_view_projection(int orthographic, const float pos[3], 
     tr[14] = -pos[2];
     yh_mat4_mul(rx, ry, a);
     yh_mat4_mul(a, rz, b);
-    yh_mat4_mul(b, tr, view);
+    yh_mat4_mul(b, tr, v);
     if (orthographic) {
-        yh_orthographic(-10.0f, 10.0f, -10.0f, 10.0f, 0.0f, 200.0f, proj);
+        yh_orthographic(-10.0f, 10.0f, -10.0f, 10.0f, 0.0f, 200.0f, proj);  // camera.zig:296
     } else {
         yh_perspective(fovy_rad, aspect, near_z, far_z, proj);
         proj[5] *= -1.0f;  // camera.zig:272
     }
-    yh_mat4_mul(proj, view, out);
+    if (view) memcpy(view, v, 64);
+    if (projection) memcpy(projection, proj, 64);
+    yh_mat4_mul(proj, v, view_projection);  // camera.zig:300-302
+}
+
+extern "C" void yh_camera_view_projection(int orthographic, const float pos[3], const float rot[3], float aspect,
+                                          float fovy_rad, float near_z, float far_z, float out[16]) {
+    yh_camera_update_matrices(orthographic, pos, rot, aspect, fovy_rad, near_z, far_z, nullptr, nullptr, out);
+}
+
+// components/transform.zig:68-70: `self.matrix.decompose() catch Mat4.Decomposed.IDENTITY` on one matrix, on the host
+// (m4_decompose is the kernels' own restatement of math3d.zig:828-981).  Returns 0 where IDENTITY was substituted.
+extern "C" int yh_mat4_decompose(const float m[16], float t[3], float q[4], float s[3]) {
+    M4 x;
+    memcpy(x.v, m, 64);
+    float o[10];
+    const bool ok = m4_decompose(x, o);
+    if (!ok) {  // math3d.zig:535-539
+        o[0] = o[1] = o[2] = 0.0f;
+        o[3] = o[4] = o[5] = 0.0f;
+        o[6] = 1.0f;
+        o[7] = o[8] = o[9] = 1.0f;
+    }
+    memcpy(t, o, 12);
+    memcpy(q, o + 3, 16);
+    memcpy(s, o + 7, 12);
+    return ok ? 1 : 0;
+}
+
+// engine/math3d.zig:418-442 — Quat.toEuler: roll / pitch / yaw in DEGREES.  atan2 / asin are libm's here; Zig 0.13 uses
+// its own std.math routines (ports of musl's atan2f / asinf), absent from this image: their last bit is "parity unpinned".
+extern "C" void yh_quat_to_euler(const float q[4], float euler_deg[3]) {
+    const float half_pi = 1.57079632679489661923f, pi = 3.14159265358979323846f;
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float sinr_cosp = 2.0f * (w * x + y * z);
+    const float cosr_cosp = 1.0f - 2.0f * (x * x + y * y);
+    const float ex = atan2f(sinr_cosp, cosr_cosp);
+    const float sinp = 2.0f * (w * y - z * x);
+    const float ey = fabsf(sinp) >= 1.0f ? copysignf(half_pi, sinp) : asinf(sinp);
+    const float siny_cosp = 2.0f * (w * z + x * y);
+    const float cosy_cosp = 1.0f - 2.0f * (y * y + z * z);
+    const float ez = atan2f(siny_cosp, cosy_cosp);
+    euler_deg[0] = ex * 180.0f / pi;  // euler.mulf(180.0).divf(std.math.pi)
+    euler_deg[1] = ey * 180.0f / pi;
+    euler_deg[2] = ez * 180.0f / pi;
+}
+
+// editor/windows/GameWindow.zig:160-161 — what the engine does per Camera entity before drawing with it:
+//   const decomposed = transform.decompose(); camera.updateMatrices(decomposed.translation, decomposed.rotation.toEuler(), aspect);
+extern "C" int yh_camera_update_from_world(int orthographic, const float world[16], float aspect, float fovy_rad,
+                                           float near_z, float far_z, float view[16], float projection[16],
+                                           float view_projection[16]) {
+    float t[3], q[4], s[3], euler[3];
+    const int ok = yh_mat4_decompose(world, t, q, s);
+    yh_quat_to_euler(q, euler);
+    yh_camera_update_matrices(orthographic, t, euler, aspect, fovy_rad, near_z, far_z, view, projection, view_projection);
+    return ok;
 }
 
 // Gribb-Hartmann, depth 0..1: L,R,B,T,N,F, each divided by |n|.

@@ -115,6 +115,9 @@ struct GpuTransformCullSystem {
     uint32_t camera_vp_offset;
     ecs_query_t* camera_query;
     ecs_entity_t frustum_camera[YH_MAX_FRUSTA];
+    int camera_pipeline;                      /* frusta from the cameras' world matrices of THIS frame (setCameraPipeline) */
+    GpuCameraLayout camera_layout;
+    float camera_aspect;
     uint32_t mesh_bounds_offset;
     int32_t mesh_vertices_offset;
     uint32_t scene_bounds_kind;               /* bounds kind the device scene was created with */
@@ -1337,14 +1340,24 @@ static int patch(GpuTransformCullSystem* s) {
         it.col_w = ecs_table_get_column_index(s->world, t, s->world_id);
         it.col_l = ecs_table_get_column_index(s->world, t, s->local_id);
         it.count = it.col_w >= 0 && it.col_l >= 0 ? (uint32_t)ecs_table_count(t) : 0u;
+        /* Disabled entities and prefabs are not matched by the system's query (flecs leaves both out unless a term asks
+         * for them; the engine exposes world.enable(e, false): ecs.zig:546), so the walk never sees their tables: a
+         * patch must not either - the rows of such a table leave, as they do on the rebuild path. */
+        if (it.count && (ecs_table_has_id(s->world, t, EcsDisabled) || ecs_table_has_id(s->world, t, EcsPrefab))) it.count = 0;
         if (it.old_batch == UINT32_MAX && !it.count) continue;
         const ecs_entity_t* ents = it.count ? ecs_table_entities(t) : NULL;
         if (it.old_batch != UINT32_MAX) {
             const Batch* b = &s->batches[it.old_batch];
             it.src = b->src;
             it.level = b->level;
-            if (it.count == b->count && memcmp(ents, s->entity_of_slot + b->slot_begin, sizeof(ecs_entity_t) * it.count) == 0)
-                continue; /* same rows in the same order (a component came and went) */
+            if (it.count == b->count && memcmp(ents, s->entity_of_slot + b->slot_begin, sizeof(ecs_entity_t) * it.count) == 0) {
+                /* Same rows in the same order (a component came and went, or rows were added and removed again): the
+                 * batch stays, but its columns may have been reallocated meanwhile - the cached pointers are dropped
+                 * and fetched afresh on first use (batch_cols). */
+                s->batches[it.old_batch].world_col = s->batches[it.old_batch].local_col = NULL;
+                s->batches[it.old_batch].up_row = NULL;
+                continue;
+            }
         } else {
             it.src = ecs_get_parent(s->world, ents[0]); /* ChildOf is part of the archetype: one parent per table */
             if (!it.src) continue;                      /* no parent: the Up term does not match this table */
@@ -1727,6 +1740,62 @@ static double now_ms(void) {
     return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
 }
 
+/* ---- the camera matrix pipeline ------------------------------------------------------------- */
+/* WorldTransform.matrix of `e` as THIS frame will leave it, before the frame has run: the three-branch rule
+ * (TransformSyncSystem.zig:60-73) replayed from the topmost holder of a WorldTransform down e's chain of `Up` sources,
+ * on the rows the frame is about to read - flecs' own (onSet hooks have set their dirty bytes), or the device's when
+ * frames ran without readback (the uploads of this frame are done by now).  The same products in the same order as the
+ * kernels (yh_mat4_mul = m4_mul, parent * local), so the result IS the row the frame writes.  Returns 1 and the matrix,
+ * 0 if e holds no WorldTransform, a negative status on a failed row fetch. */
+static int camera_world_this_frame(GpuTransformCullSystem* s, ecs_entity_t e, float out[16]) {
+    ecs_entity_t chain[YH_MAX_LEVELS + SPARE_LEVELS];
+    uint32_t chain_slot[YH_MAX_LEVELS + SPARE_LEVELS];
+    uint32_t depth = 0, slot;
+    ecs_entity_t top = e;
+    while (slot_lookup(s, top, &slot)) { /* rows of this system: up through the Up sources of their tables */
+        if (depth == YH_MAX_LEVELS + SPARE_LEVELS) return YH_ERR_STATE;
+        chain[depth] = top;
+        chain_slot[depth++] = slot;
+        top = batch_of_slot(s, slot)->src;
+    }
+    /* `top` holds a WorldTransform and no slot: the scene root (GameApp.zig:77,95), or e itself without a LocalTransform */
+    const uint8_t* row = top ? (const uint8_t*)ecs_get_id(s->world, top, s->world_id) : NULL;
+    if (!row) return 0;
+    float pm[16];
+    memcpy(pm, row, 64);
+    int pdirty = row[64] != 0;
+    for (uint32_t i = depth; i-- > 0;) {
+        uint8_t wrow[ROW], lrow[ROW];
+        if (s->host_stale) {
+            int rc;
+            if ((rc = yh_download_world_aos68(s->scene, wrow, chain_slot[i], 1)) != YH_OK ||
+                (rc = yh_download_local_aos68(s->scene, lrow, chain_slot[i], 1)) != YH_OK)
+                return rc;
+        } else {
+            const void* w = ecs_get_id(s->world, chain[i], s->world_id);
+            const void* l = ecs_get_id(s->world, chain[i], s->local_id);
+            if (!w || !l) return 0;
+            memcpy(wrow, w, ROW);
+            memcpy(lrow, l, ROW);
+        }
+        const int ld = lrow[64] != 0, wd = wrow[64] != 0;
+        if (!pdirty && !ld && !wd) { /* :62-64: the row stays as it is */
+            memcpy(pm, wrow, 64);
+        } else if (ld || pdirty) { /* :67-68 */
+            float l[16], w[16];
+            memcpy(l, lrow, 64);
+            yh_mat4_mul(pm, l, w);
+            memcpy(pm, w, 64);
+            pdirty = 1;
+        } else { /* :69-72: the world matrix was edited; the local one is re-derived from it, the world row stays */
+            memcpy(pm, wrow, 64);
+            pdirty = 1;
+        }
+    }
+    memcpy(out, pm, 64);
+    return 1;
+}
+
 static void run(ecs_iter_t* it) {
     GpuTransformCullSystem* s = (GpuTransformCullSystem*)it->ctx;
     int rc = YH_OK;
@@ -1825,26 +1894,6 @@ static void run(ecs_iter_t* it) {
         s->status = rc;
         return;
     }
-    /* frusta: the ones handed over with setFrusta, else one per Camera entity, from Camera.view_projection as the
-     * engine last updated it (components/camera.zig:300-302; GameWindow.zig:154-178 draws once per such entity) */
-    if (!s->n_explicit && s->camera_query) {
-        uint32_t nf = 0;
-        ecs_iter_t cit = ecs_query_iter(s->world, s->camera_query);
-        while (ecs_query_next(&cit)) {
-            const int32_t col = cit.table ? ecs_table_get_column_index(s->world, cit.table, s->camera_id) : -1;
-            if (col < 0) continue;
-            const size_t size = ecs_table_get_column_size(cit.table, col);
-            const uint8_t* cams = (const uint8_t*)ecs_table_get_column(cit.table, col, cit.offset);
-            for (int32_t r = 0; r < cit.count && nf < YH_MAX_FRUSTA; ++r) {
-                float vp[16];
-                memcpy(vp, cams + (size_t)r * size + s->camera_vp_offset, 64);
-                yh_extract_planes(vp, s->planes + 24 * nf);
-                s->frustum_camera[nf++] = cit.entities[r];
-            }
-        }
-        s->n_frusta = nf;
-    }
-    const uint32_t cull_flags = s->n_frusta ? 0u : YH_FRAME_NO_CULL;
     const double t_inputs = now_ms();
     if (!s->incremental || rebuilt) {
         /* whole columns up; in plain mode whole columns down again */
@@ -1871,6 +1920,43 @@ static void run(ecs_iter_t* it) {
             s->last_up_rows += m;
         }
     }
+    /* frusta: the ones handed over with setFrusta, else one per Camera entity - from this frame's world matrix of the
+     * camera (setCameraPipeline: GameWindow.zig:160-161 done before the frame instead of after it), or from
+     * Camera.view_projection as the engine last updated it (components/camera.zig:300-302).  After the uploads: the
+     * device rows the replay may have to read (readback off) are this frame's inputs by now. */
+    if (!s->n_explicit && s->camera_query) {
+        uint32_t nf = 0;
+        ecs_iter_t cit = ecs_query_iter(s->world, s->camera_query);
+        while (ecs_query_next(&cit)) {
+            const int32_t col = cit.table ? ecs_table_get_column_index(s->world, cit.table, s->camera_id) : -1;
+            if (col < 0) continue;
+            const size_t size = ecs_table_get_column_size(cit.table, col);
+            uint8_t* cams = (uint8_t*)ecs_table_get_column(cit.table, col, cit.offset);
+            for (int32_t r = 0; r < cit.count && nf < YH_MAX_FRUSTA; ++r) {
+                uint8_t* cam = cams + (size_t)r * size;
+                float vp[16], wm[16];
+                if (s->camera_pipeline && (rc = camera_world_this_frame(s, cit.entities[r], wm)) == 1) {
+                    const GpuCameraLayout* L = &s->camera_layout;
+                    float opt[3], view[16], proj[16];
+                    memcpy(opt, cam + L->options_offset, sizeof opt); /* PerspectiveOptions{fovy_rad, near, far} */
+                    yh_camera_update_from_world(cam[L->kind_offset] == 1, wm, s->camera_aspect, opt[0], opt[1], opt[2], view, proj, vp);
+                    memcpy(cam + L->view_offset, view, 64); /* camera.zig:266, 271-272, 301 */
+                    memcpy(cam + L->projection_offset, proj, 64);
+                    memcpy(cam + L->view_projection_offset, vp, 64);
+                } else if (s->camera_pipeline && rc < 0) {
+                    while (ecs_query_next(&cit)) {} /* the iterator owns resources: run it to its end */
+                    s->status = rc;
+                    return;
+                } else {
+                    memcpy(vp, cam + s->camera_vp_offset, 64);
+                }
+                yh_extract_planes(vp, s->planes + 24 * nf);
+                s->frustum_camera[nf++] = cit.entities[r];
+            }
+        }
+        s->n_frusta = nf;
+    }
+    const uint32_t cull_flags = s->n_frusta ? 0u : YH_FRAME_NO_CULL;
     const double t_up = now_ms();
     rc = yh_frame(s->scene, s->planes, s->n_frusta, cull_flags); /* returns when the device is done */
     const double t_frame = now_ms();
@@ -1980,6 +2066,9 @@ ecs_entity_t GpuTransformCullSystem_registerTo(ecs_world_t* world, ecs_entity_t 
         ecs_observer_desc_t od;
         memset(&od, 0, sizeof od);
         od.query.terms[0].id = k == 0 ? EcsWildcard : ecs_pair(EcsWildcard, EcsWildcard);
+        /* world.enable(e, false) (ecs.zig:546) adds the Disabled tag: the row moves to a table no query matches by
+         * default - not an observer's either, which would then never hear of it leaving (or of it coming back) */
+        od.query.flags = EcsQueryMatchDisabled | EcsQueryMatchPrefab;
         od.events[0] = EcsOnAdd;
         od.events[1] = EcsOnRemove;
         od.callback = note_structure;
@@ -1990,6 +2079,7 @@ ecs_entity_t GpuTransformCullSystem_registerTo(ecs_world_t* world, ecs_entity_t 
         ecs_observer_desc_t od;
         memset(&od, 0, sizeof od);
         od.query.terms[0].id = k == 0 ? local_transform : world_transform;
+        od.query.flags = EcsQueryMatchDisabled | EcsQueryMatchPrefab;
         od.events[0] = EcsOnTableCreate;
         od.events[1] = EcsOnTableDelete;
         od.callback = note_table;
@@ -2102,12 +2192,37 @@ int GpuTransformCullSystem_setCameraComponent(GpuTransformCullSystem* s, ecs_ent
     ecs_query_desc_t qd;
     memset(&qd, 0, sizeof qd);
     qd.terms[0].id = camera;
-    qd.terms[0].inout = EcsIn;
+    qd.terms[0].inout = EcsInOut; /* the camera pipeline writes the three matrices, as updateMatrices does */
     qd.cache_kind = EcsQueryCacheAuto;
     s->camera_query = ecs_query_init(s->world, &qd);
     if (!s->camera_query) return YH_ERR_BAD_ARG;
     s->camera_id = camera;
     s->camera_vp_offset = view_projection_offset;
+    return YH_OK;
+}
+
+int GpuTransformCullSystem_setCameraPipeline(GpuTransformCullSystem* s, const GpuCameraLayout* layout, float aspect) {
+    if (!s) return YH_ERR_BAD_ARG;
+    if (!layout) {
+        s->camera_pipeline = 0;
+        return YH_OK;
+    }
+    if (!s->camera_id) return YH_ERR_STATE; /* setCameraComponent first */
+    const ecs_type_info_t* ti = ecs_get_type_info(s->world, s->camera_id);
+    const uint64_t size = ti ? (uint64_t)ti->size : 0;
+    if ((uint64_t)layout->kind_offset + 1 > size || (uint64_t)layout->options_offset + 12 > size ||
+        (uint64_t)layout->view_offset + 64 > size || (uint64_t)layout->projection_offset + 64 > size ||
+        (uint64_t)layout->view_projection_offset + 64 > size || !(aspect > 0.0f))
+        return YH_ERR_BAD_ARG;
+    s->camera_layout = *layout;
+    s->camera_aspect = aspect;
+    s->camera_pipeline = 1;
+    return YH_OK;
+}
+
+int GpuTransformCullSystem_setCameraAspect(GpuTransformCullSystem* s, float aspect) {
+    if (!s || !(aspect > 0.0f)) return YH_ERR_BAD_ARG;
+    s->camera_aspect = aspect;
     return YH_OK;
 }
 

@@ -47,7 +47,7 @@ int GpuTransformCullSystem_setFrusta(GpuTransformCullSystem* s, const float* pla
  * (engine/components/camera.zig:54-66: 176 in the reference's layout).  Every frame culls against one frustum per
  * Camera entity (query order, at most YH_MAX_FRUSTA), planes taken from its view_projection as the engine last updated
  * it (camera.zig:300-302; the reference does that at draw time, GameWindow.zig:154-178, so a camera that moved is seen
- * one frame late unless the engine updates matrices before world.progress).  frustumCamera(f): the entity behind
+ * one frame late - unless setCameraPipeline, below, is on).  frustumCamera(f): the entity behind
  * frustum f.  Frusta handed over with setFrusta take precedence; setFrusta(NULL, 0) returns to the cameras.
  * setMeshComponent: the id of the Mesh component (`Mesh{ ref: *meshes.Mesh }`, engine/components/mesh.zig), and
  * @offsetOf(meshes.Mesh, "bounds") / @offsetOf(meshes.Mesh, "vertices_count") inside what `ref` points to
@@ -57,6 +57,27 @@ int GpuTransformCullSystem_setFrusta(GpuTransformCullSystem* s, const float* pla
  * sets and structural changes by themselves, invalidateBounds re-reads them when a mesh asset itself was reloaded.
  * setBounds stays as a per-entity override.  At most 65535 distinct meshes + overrides (YH_ERR_CAPACITY beyond). */
 int GpuTransformCullSystem_setCameraComponent(GpuTransformCullSystem* s, ecs_entity_t camera, uint32_t view_projection_offset);
+/* The camera matrix pipeline: THIS frame's frusta from the cameras' own transforms.  The reference
+ * updates a camera's matrices at draw time from the WorldTransform the frame just wrote
+ * (editor/windows/GameWindow.zig:154-178: transform.decompose() -> rotation.toEuler() -> camera.updateMatrices(pos,
+ * euler, aspect)); culling has to know them before the frame runs.  With a layout set, every frame first works out each
+ * Camera entity's world matrix of this frame on the host - the three-branch rule (TransformSyncSystem.zig:60-73)
+ * replayed down its chain of `Up` ancestors over the rows the frame is about to read: at most `depth` products per
+ * camera, left to right like the kernels, so the value equals the row the frame then writes - runs
+ * yh_camera_update_from_world on it, writes view / projection / view_projection into the component as updateMatrices
+ * does (components/camera.zig:161-166, 253-302) and culls against those planes.  Without a layout (the default) the
+ * frusta come from view_projection as the engine last left it: a camera that moved is seen one frame late.
+ * Offsets inside the Camera component (components/camera.zig:42-66): kind = @offsetOf(Camera, "opts") (+ 0: the u8
+ * CameraKind, 0 perspective / 1 orthographic), options = offset of `opts.data` (PerspectiveOptions{fovy_rad, near,
+ * far}; an orthographic camera's options are not read, camera.zig:291-298 ignores them too), then the three matrices:
+ * 0 / 4 / 48 / 112 / 176 in the reference's layout.  aspect: GameWindow.zig:155, game_view_size.x / .y; the host
+ * calls setCameraAspect when the view is resized.  Cameras the system does not hold a slot for (no LocalTransform, or
+ * no WorldTransform at all) use their WorldTransform as flecs holds it, or keep their stored view_projection.   */
+typedef struct GpuCameraLayout {
+    uint32_t kind_offset, options_offset, view_offset, projection_offset, view_projection_offset;
+} GpuCameraLayout;
+int GpuTransformCullSystem_setCameraPipeline(GpuTransformCullSystem* s, const GpuCameraLayout* layout /* NULL: off */, float aspect);
+int GpuTransformCullSystem_setCameraAspect(GpuTransformCullSystem* s, float aspect);
 int GpuTransformCullSystem_setMeshComponent(GpuTransformCullSystem* s, ecs_entity_t mesh, uint32_t bounds_offset,
                                             int32_t vertices_count_offset);
 int GpuTransformCullSystem_invalidateBounds(GpuTransformCullSystem* s);

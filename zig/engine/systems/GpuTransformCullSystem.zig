@@ -28,6 +28,9 @@ extern fn GpuTransformCullSystem_registerTo(
     out_state: *?*State,
 ) c.ecs_entity_t;
 extern fn GpuTransformCullSystem_setCameraComponent(s: *State, camera: c.ecs_entity_t, view_projection_offset: u32) c_int;
+pub const CameraLayout = extern struct { kind_offset: u32, options_offset: u32, view_offset: u32, projection_offset: u32, view_projection_offset: u32 };
+extern fn GpuTransformCullSystem_setCameraPipeline(s: *State, layout: ?*const CameraLayout, aspect: f32) c_int;
+extern fn GpuTransformCullSystem_setCameraAspect(s: *State, aspect: f32) c_int;
 extern fn GpuTransformCullSystem_setMeshComponent(s: *State, mesh: c.ecs_entity_t, bounds_offset: u32, vertices_count_offset: i32) c_int;
 extern fn GpuTransformCullSystem_invalidateBounds(s: *State) c_int;
 extern fn GpuTransformCullSystem_frustumCamera(s: *const State, frustum: u32) c.ecs_entity_t;
@@ -100,6 +103,27 @@ pub fn registerTo(world: ecs.World) ecs.Entity {
             @offsetOf(meshes.Mesh, "vertices_count"),
         );
     return sys;
+}
+
+/// The camera matrix pipeline: every frame derives each Camera entity's view / projection / view_projection from the
+/// WorldTransform that frame is about to write - what GameWindow.zig:160-161 does at draw time
+/// (`transform.decompose()` -> `rotation.toEuler()` -> `camera.updateMatrices(pos, euler, aspect)`) - writes them into
+/// the component and culls against THIS frame's frusta.  `aspect` is GameWindow.zig:155's game_view_size.x / .y; call
+/// again (or `setCameraAspect`) when the game view is resized.  Off (the default): frusta come from view_projection as
+/// the last draw left it, one frame late for a camera that moved.
+pub fn setCameraPipeline(on: bool, aspect: f32) void {
+    const CameraOptions = @TypeOf(@as(Camera, undefined).opts);
+    const layout = CameraLayout{
+        .kind_offset = @offsetOf(Camera, "opts") + @offsetOf(CameraOptions, "kind"),
+        .options_offset = @offsetOf(Camera, "opts") + @offsetOf(CameraOptions, "data"),
+        .view_offset = @offsetOf(Camera, "view"),
+        .projection_offset = @offsetOf(Camera, "projection"),
+        .view_projection_offset = @offsetOf(Camera, "view_projection"),
+    };
+    last_status = GpuTransformCullSystem_setCameraPipeline(state.?, if (on) &layout else null, aspect);
+}
+pub fn setCameraAspect(aspect: f32) void {
+    last_status = GpuTransformCullSystem_setCameraAspect(state.?, aspect);
 }
 
 /// Override: bounds of one entity that are not its mesh's (engine/meshes.zig:72-95 `Mesh.bounds` is the default).
