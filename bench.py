@@ -97,13 +97,21 @@ def algorithmic_bytes(wl, lo, parent, first, end, n_frusta, list_entries):
     return float(b), 4.0 * float(list_entries)
 
 
-def cpu_baseline(wl, n, lo, parent, planes, seconds):
-    """The reference CPU systems (oracle port: AoS 68-byte columns, one batch per table, forward branch on every
-    row + both dirty sweeps, then the cull), single thread as the reference runs them, on the host cores of
-    this box.  Only this leg touches oracle/."""
+CPU_SAMPLE = {  # entities of the CPU leg's sample per workload: the workload's own shape, bounded
+    "cfg2": 1_000_000,          # the whole workload: 1M entities, 8 levels
+    "cfg3": 1_000_000,          # 1M of the 16M flat entities, all 5 frusta
+    "cfg4": 12_500_000 // 16,   # a 1/16 sample of one GPU's 12.5M-entity 8-level shard: EXTRAPOLATED
+    "cfg5": 1_000_000,          # 1M of the 256M instances, 16 instanced AABBs
+}
+
+
+def cpu_baseline(name, wl, n, lo, parent, planes, seconds):
+    """The reference CPU systems (oracle port: AoS 68-byte columns, one batch per table = per run of equal parent,
+    forward branch on every row + both dirty sweeps, then the cull), single thread as the reference runs them and on
+    all host cores, on a bounded sample of THIS workload's shape.  Only this leg touches oracle/."""
     from oracle import pyoracle as oracle
 
-    n_s = min(n, 1_000_000)  # bounded sample: at most 1M entities per CPU frame
+    n_s = min(n, CPU_SAMPLE.get(name, 1_000_000))
     if n_s != n:
         lo_s = oracle.synth_level_offsets(n_s, len(lo) - 1)
         par_s = oracle.synth_parents(lo_s)
@@ -143,7 +151,7 @@ def cpu_baseline(wl, n, lo, parent, planes, seconds):
             "ns_per_entity": round(med / n_s * 1e9, 2),
             "sample": f"{len(times)} frames of a {n_s}-entity {len(lo_s) - 1}-level scene, {planes.shape[0]} frusta "
                       f"(median; gcc -O2 -ffp-contract=off; AoS-68 propagate + 2 dirty sweeps + cull)"
-                      + ("" if n_s == n else f"; sampled from the {n}-entity workload"),
+                      + ("" if n_s == n else f"; a {n_s}/{n} sample of the workload's shape: the rate is EXTRAPOLATED to the full size"),
         }
     return out
 
@@ -237,6 +245,10 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
+class CommFailure(RuntimeError):
+    """The library's RCCL communicator could not be brought up (or failed its end-to-end check) on some rank."""
+
+
 class Job:
     """What every workload of this process shares: the context, the ranks, the transport."""
 
@@ -249,9 +261,8 @@ class Job:
         self.torch = None
         self.ctx = None
         self.info = None
-        self.use_lib_comm = True
         self.comm_up = False
-        self.comm_err = ""
+        self.rccl = ""  # which RCCL the library resolved (yh_comm_describe), next to torch's
 
     def barrier(self):
         self.ctx.wait()
@@ -343,42 +354,35 @@ def run_workload(job, name, steps, warmup, headline, entities=0):
             job.comm_up = True
         collective = "rccl (library, collective stream), one-rank rehearsal"
     if world_size > 1:
-        # product path: the library's own RCCL communicator.  If it cannot be brought up on every rank, stand by with
-        # torch.distributed ("nccl" = RCCL as well) over downloaded lists and say so in the report.
-        dist, torch = job.dist, job.torch
+        # The product's only transport: the library's own RCCL communicator.  If it cannot be brought up and checked end
+        # to end on EVERY rank the job has no result: CommFailure ends it with "value": null (main), never a stand-by.
+        dist = job.dist
         err = ""
         try:
             with stdout_to_stderr():
-                if not job.comm_up and job.use_lib_comm:
+                if not job.comm_up:
                     ids = [Context.comm_unique_id() if rank == 0 else None]
                     dist.broadcast_object_list(ids, src=0)
                     ctx.comm_init(world_size, rank, ids[0])
                     job.comm_up = True
-                if job.use_lib_comm:
-                    scene.frame(planes, _lib.YH_FRAME_ALL_DIRTY)
-                    scene.allgather_draw_lists()        # exact-size exchange (host sync): checks the communicator end to end
-                    scene.allgather_draw_lists_async()  # the pipelined exchange the timed frames use
-                    scene.gathered_counts(F)
+                scene.frame(planes, _lib.YH_FRAME_ALL_DIRTY)
+                scene.allgather_draw_lists()        # exact-size exchange (host sync): checks the communicator end to end
+                scene.allgather_draw_lists_async()  # the pipelined exchange the timed frames use
+                scene.gathered_counts(F)
             ok = 1
         except Exception as ex:  # noqa: BLE001
-            ok, err = 0, str(ex)
-        if job.use_lib_comm and not job.all_ok(ok):
-            job.use_lib_comm = False
-            job.comm_err = err
+            ok, err = 0, f"rank {rank}: {ex}"
+        if not job.all_ok(ok):
+            raise CommFailure(err or "the library's RCCL communicator failed on another rank")
         collective = ("rccl (library, collective stream): one ncclAllGather of the frame's VISIBILITY WORDS (n/8 bytes per "
                       "frustum and rank, not index lists: 20-32x fewer bytes over xGMI), every rank expands all ranks' words "
-                      "into the gathered draw lists itself (its own part included: the frames pass YH_FRAME_LISTS_ON_DEMAND); runs beside the next frames" if job.use_lib_comm
-                      else f"torch.distributed nccl stand-by (library communicator failed: {job.comm_err[:120]})")
+                      "into the gathered draw lists itself (its own part included: the frames pass YH_FRAME_LISTS_ON_DEMAND); "
+                      f"runs beside the next frames; {job.rccl}")
 
     def step():
         scene.frame(planes, flags)
         if gather:
-            if job.use_lib_comm:
-                scene.allgather_draw_lists_async()
-            else:
-                from yume_amd import shard
-
-                shard.allgather_draw_lists_torch([scene.draw_list(f) for f in range(F)], device="cuda")
+            scene.allgather_draw_lists_async()
 
     def timed(k):
         job.barrier()
@@ -441,13 +445,26 @@ def run_workload(job, name, steps, warmup, headline, entities=0):
         if len(same) > 1 and traffic is not None:
             traffic, traffic_src = None, f"{traffic_src}: per-name mean {traffic:.0f} B covers {len(same)} launches of the frame"
         frac = achieved / HBM_PEAK_GBPS
-        # what bounds the launch: a streaming kernel is HBM-bound when it runs near the measured copy ceiling
-        # (0.78 of the 8 TB/s figure); the 5-frusta cull of cfg3 is bound by vector-ALU issue instead
-        bound = "hbm"
+        # What bounds the launch.  A scene whose frame-to-frame working set exceeds the 256 MB Infinity Cache streams
+        # from HBM: its yardstick is the HBM peak.  A smaller one is served by the cache: the HBM peak says nothing
+        # there, so a plain read + write stream over a working set of the same size and read/write mix is measured on
+        # this GPU, in this run (yh_stream_probe), and the launch is quoted against THAT (`cache_ceiling`).
+        bound = "infinity_cache" if cache_assisted else "hbm"
         note = None
+        cache = None
         if cache_assisted:
-            note = (f"cache-assisted: the frame's {working_set / 1e6:.0f} MB working set stays in the 256 MB Infinity Cache from "
-                    "one frame to the next, so `achieved` is not an HBM rate")
+            reads = own_frame - n * 64.0 - F * (n / 8.0 + n / 64.0)
+            writes = working_set - reads
+            probe_ms = ctx.stream_probe(reads, writes, 200)
+            ceiling = working_set / (probe_ms * 1e-3) / 1e9
+            cache = {"cache_ceiling": round(ceiling, 1), "cache_ceiling_unit": "GB/s",
+                     "cache_ceiling_probe": f"yh_stream_probe: {reads / 1e6:.1f} MB read + {writes / 1e6:.1f} MB written per launch, "
+                                            f"the same buffers 200 times, {probe_ms * 1e3:.2f} us per launch (plain 16-byte loads and stores)",
+                     "frac_of_cache_ceiling": round(achieved / ceiling, 4),
+                     "frame_frac_of_cache_ceiling": round(working_set / (ms_frame * 1e-3) / 1e9 / ceiling, 4)}
+            note = (f"cache-resident: the frame's {working_set / 1e6:.0f} MB working set stays in the 256 MB Infinity Cache from one "
+                    "frame to the next, so `achieved` is not an HBM rate and `frac` (of the HBM peak) is kept for the record only; "
+                    "the yardstick is `cache_ceiling`")
         roofline = {
             "bound": bound, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(frac, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -463,6 +480,8 @@ def run_workload(job, name, steps, warmup, headline, entities=0):
             "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
             "frame_frac": round((own_frame + lists_frame) / (ms_frame * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
         }
+        if cache:
+            roofline.update(cache)
         if note:
             roofline["note"] = note
     scene.set_kernel_timing(False)
@@ -485,7 +504,6 @@ def run_workload(job, name, steps, warmup, headline, entities=0):
         "visible_fraction": [round(float(c) / n, 4) for c in counts[:F]],
         "boundary_cases": [int(x) for x in bcounts[:F]],
     }
-    extra = None
     if headline:
         # un-instrumented pass of the same K steps (reported beside, never as `value`)
         elapsed_plain = timed(steps)
@@ -495,13 +513,103 @@ def run_workload(job, name, steps, warmup, headline, entities=0):
         for _ in range(min(20, steps)):
             a = time.perf_counter()
             scene.frame(planes, _lib.YH_FRAME_ALL_DIRTY)
-            if gather and job.use_lib_comm:
+            if gather:
                 scene.allgather_draw_lists()
             lat.append(time.perf_counter() - a)
         rec["frame_latency_ms_synced_median"] = round(float(np.median(lat)) * 1e3, 5)
-        extra = (wl, n, lo, parent, planes)
+    # what the CPU leg of this workload needs (the hierarchy itself only where the leg runs the workload whole)
+    extra = (name, wl, n, lo, parent if n <= CPU_SAMPLE.get(name, 0) else None, planes)
     scene.close()
     return rec, extra
+
+
+def run_mat4(job):
+    """The drop-in's own path (rule A3 literally, on imported flecs columns): a 12.5M-entity 8-level Mat4 scene - cfg4's
+    per-GPU shard held as 68-byte LocalTransform / WorldTransform columns instead of TRS -, every row dirty, change
+    tracking on (what GpuTransformCullSystem runs: the frame also files every row it touched for the readback).
+    One launch of k_level_mat4 / k_chain_mat4 per level group, k_sweep_dirty, the expansions of the draw list and of
+    the two change lists."""
+    from yume_amd import Scene, _lib, synth
+
+    ctx = job.ctx
+    n, levels = 12_500_000, 8
+    lo = synth.level_offsets(n, levels)
+    par = synth.parents(lo)
+    planes = synth.main_camera_planes().reshape(1, 24)
+    with Scene(ctx, n, n_levels=levels, n_frusta=1) as t:  # locals composed on a TRS scene of the same synthetic inputs
+        t.upload_hierarchy(par, lo)
+        t.fill_synthetic()
+        local_m = t.compose()
+        mins, maxs = t.download_aabb()
+    T68 = np.dtype([("m", np.float32, 16), ("dirty", np.uint8), ("pad", np.uint8, 3)])
+    col = np.zeros(n, T68)
+    col["m"] = local_m.T
+    col["dirty"] = 1
+    del local_m
+    s = Scene(ctx, n, n_levels=levels, n_frusta=1, local_kind=_lib.YH_LOCAL_MAT4)
+    s.upload_hierarchy(par, lo)
+    s.upload_aabb(mins, maxs)
+    s.upload_local_aos68(col)
+    del col, mins, maxs
+    s.track_changes(True)
+    flags = _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC
+
+    def timed(k):
+        job.barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            s.frame(planes, flags)
+        job.barrier()
+        return time.perf_counter() - t0
+
+    s.set_kernel_timing(1)  # calibration, untimed: events around every launch (they read 3-5 us long on launches of ~65 us)
+    for _ in range(10):
+        s.frame(planes, flags)
+    ms_all, _ = s.group_timings()
+    groups = s.groups()
+    names = s.group_kernel_names()
+    s.set_kernel_timing(0)
+    for _ in range(5):
+        s.frame(planes, flags)
+    probe = timed(10) / 10
+    steps = int(max(20, math.ceil(SUB_MIN_TIMED_S / max(probe, 1e-7))))
+    elapsed = timed(steps)
+    counts, _b = s.counts()
+    nw, nl = s.changed_counts()
+    # compulsory bytes of the all-dirty frame: local row 64 + both dirty bytes 2 + parent index 4 (levels > 0) + AABB 24 in,
+    # 64 (+1 dirty byte) per distinct parent per level in, world row 64 + both dirty bytes cleared 2 out; stage 3: one bit
+    # per entity in each of the three masks (visible, world changed, local changed) + their count bytes, 4 B per listed slot
+    b = n * (64 + 2 + 24 + 64 + 2) + 4 * (n - int(lo[1]))
+    for k in range(1, levels):
+        b += 65 * int(np.count_nonzero(np.diff(par[int(lo[k]):int(lo[k + 1])])) + 1)
+    b += 3 * (n / 8.0 + n / 64.0) + 4.0 * (float(counts[0]) + nw + nl)
+    ms_frame = elapsed / steps * 1e3
+    g = int(np.argmax(ms_all[: len(groups)]))
+    first, end = int(groups[g][2]), int(groups[g][3])
+    own = (end - first) * (64 + 2 + 24 + 4 + 64 + 1 + 1 / 8 + 1 / 64) + 65 * int(np.count_nonzero(np.diff(par[first:end])) + 1)
+    rec = {
+        "value": round(n * steps / elapsed / 1e6, 2), "unit": "Mentities/s", "steps": steps, "ms_per_step": round(ms_frame, 5),
+        "timed_region_ms": round(elapsed * 1e3, 3), "scaling": "weak",
+        "config": {"workload": "mat4: the drop-in's literal-rule path - 12.5M-entity 8-level scene held as 68-byte LocalTransform / "
+                               "WorldTransform columns (YH_LOCAL_MAT4), every row dirty, change tracking on",
+                   "entities_per_gpu": n, "levels": levels, "frusta": 1, "launches_per_frame": int(len(groups)),
+                   "level_groups": [[int(x) for x in q] for q in groups], "kernels": names},
+        "roofline": {"bound": "hbm", "achieved": round(own / (float(ms_all[g]) * 1e-3) / 1e9, 1) if ms_all[g] > 0 else 0.0,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(own / (float(ms_all[g]) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms_all[g] > 0 else 0.0,
+                     "traffic": None, "kernel_symbol": names[g] if g < len(names) else "",
+                     "kernel_entities": end - first, "kernel_ms": round(float(ms_all[g]), 5),
+                     "kernel_ms_source": "HIP events recorded around the launch, 10 untimed calibration frames (they read 3-5 us long)",
+                     "algorithmic_bytes_per_launch": own,
+                     "launch_ms_all_calibration": [round(float(x), 5) for x in ms_all[: len(groups)]],
+                     "frame_frac": round(b / (ms_frame * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+        "frame_hbm_frac": round(b / (ms_frame * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "frame_algorithmic_bytes_per_entity": round(b / n, 2),
+        "visible_fraction": [round(float(counts[0]) / n, 4)],
+        "changed_rows": {"world": int(nw), "local": int(nl)},
+    }
+    s.close()
+    return rec
 
 
 def main():
@@ -540,7 +648,28 @@ def main():
     gc.collect()
     gc.disable()
 
-    head, extra = run_workload(job, args.workload, args.steps, args.warmup, True, args.entities)
+    job.rccl = ""
+    if world_size > 1:
+        v = torch.cuda.nccl.version()
+        job.rccl = f"library: {Context.comm_describe()}; torch: rccl {'.'.join(str(x) for x in v)}"
+        os.environ.setdefault("YUME_HIP_COMM_LOG", "1")  # one line per rank on stderr when the communicator comes up
+        print(f"bench.py rank {rank}: {job.rccl}", file=sys.stderr, flush=True)
+
+    def no_result(err):
+        """N > 1 and the library's communicator is not there: the job has no value.  Said in the one JSON line, loudly."""
+        if rank == 0:
+            print(json.dumps({"metric": "Mentities/s transformed+culled per frame", "value": None, "unit": "Mentities/s",
+                              "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                              "higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": args.workload, "rccl": job.rccl},
+                              "error": f"the library's RCCL communicator could not be used on every rank: {err[:400]}"}), flush=True)
+        sys.stdout.flush()
+        os._exit(3)  # (not sys.exit: a rank stuck inside a half-built communicator would hang the interpreter's teardown)
+
+    try:
+        head, extra = run_workload(job, args.workload, args.steps, args.warmup, True, args.entities)
+    except CommFailure as ex:
+        no_result(str(ex))
     result = {
         "metric": "Mentities/s transformed+culled per frame",
         "value": head["value"],
@@ -580,25 +709,39 @@ def main():
     if subs:
         threading.Thread(target=watchdog, daemon=True).start()
     t_sub = time.perf_counter()
+    cpu_legs = [extra]
     for w in subs:
         late = job.max_over_ranks(time.perf_counter() - t_sub) > SUB_BUDGET_S
         if late:
             result["workloads"][w] = {"skipped": f"sub-record budget of {SUB_BUDGET_S:.0f} s used up"}
             continue
         try:
-            rec, _ = run_workload(job, w, 0, 20 if WORKLOADS[w]["n"] <= 2_000_000 else 5, False)
+            rec, sub_extra = run_workload(job, w, 0, 20 if WORKLOADS[w]["n"] <= 2_000_000 else 5, False)
+            cpu_legs.append(sub_extra)
             ok, err = True, ""
         except Exception as ex:  # noqa: BLE001
             rec, ok, err = None, False, str(ex)
         result["workloads"][w] = rec if ok else {"error": err[:300]}
         if not job.all_ok(ok):  # a rank failed: the others would wait for it in the next workload's collectives
             break
+    # the drop-in's own path (Mat4 columns, literal rule, change tracking): one GPU only - it is what ONE engine process runs
+    if subs and world_size == 1 and not args.sub and "_error" not in result["workloads"]:
+        try:
+            result["workloads"]["mat4"] = run_mat4(job)
+        except Exception as ex:  # noqa: BLE001
+            result["workloads"]["mat4"] = {"error": str(ex)[:300]}
     done.set()
 
     gc.enable()
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
-        wl, n, lo, parent, planes = extra
-        result.update(cpu_baseline(wl, n, lo, parent, planes, args.cpu_seconds))
+        # every workload's CPU leg on a sample of its own shape: the headline's gets --cpu-seconds, each
+        # sub-record's a third of that
+        for k, (name, wl, n, lo, parent, planes) in enumerate(cpu_legs):
+            legs = cpu_baseline(name, wl, n, lo, parent, planes, args.cpu_seconds if k == 0 else args.cpu_seconds / 3)
+            if k == 0:
+                result.update(legs)
+            elif isinstance(result["workloads"].get(name), dict):
+                result["workloads"][name].update(legs)
         result["cpu_baseline_in_flecs"] = cpu_baseline_flecs(8)
     elif rank == 0:
         result["cpu_baseline"] = None

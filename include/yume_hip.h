@@ -294,6 +294,12 @@ int yh_scene_get_group_timings(yh_scene* s, float* mean_ms, uint32_t* samples, u
 /* The kernel each group's launch of the LAST frame ran, spelled as rocprofv3's kernel trace spells it (one per
  * line, group order): the harness looks a launch's counters up by the name the library really dispatched.   */
 int yh_scene_get_group_kernel_names(yh_scene* s, char* buf, uint64_t cap, uint32_t* n_groups);
+/* Measurement harness (no reference counterpart): mean device time of `launches` back-to-back launches of a plain
+ * stream kernel that reads read_bytes and writes write_bytes (16-byte accesses, ordinary loads and stores) of buffers
+ * that stay the same from launch to launch - so a working set that fits the 256 MB Infinity Cache is served from it.
+ * bench.py divides a cache-resident workload's rate by what this reaches on a working set of the same size and mix
+ * (`roofline.cache_ceiling`): the HBM peak is no yardstick there.  Allocates and frees its buffers; synchronises. */
+int yh_stream_probe(yh_ctx* ctx, uint64_t read_bytes, uint64_t write_bytes, uint32_t launches, float* mean_ms);
 /* Hierarchy launches (TRS scenes): levels are cut into groups of consecutive levels, one kernel launch per
  * group; inside a group an entity re-derives its ancestors' matrices (a walk up the parent chain) instead of
  * waiting for a launch boundary.  Results do not depend on the plan.  yh_scene_set_grouping: exactly
@@ -369,6 +375,11 @@ int yh_shard_extract(const uint32_t* parent_index, const uint32_t* level_offsets
 int yh_comm_unique_id(void* out_id /* YH_UNIQUE_ID_BYTES */);
 int yh_comm_init(yh_ctx* ctx, int n_ranks, int rank, const void* unique_id);
 void yh_comm_destroy(yh_ctx* ctx);
+/* Which RCCL the library resolved ("rccl 2.x.y from /path/librccl.so.1"): RCCL is dlopen'ed by SONAME, so inside a
+ * process that already holds one (torch bundles its own) the loader hands the same copy out again; two different
+ * copies in one process would show here.  YUME_HIP_COMM_LOG=1 makes yh_comm_init print the same on stderr.  Loads
+ * RCCL if it is not loaded yet (YH_ERR_RCCL when there is none).                                                 */
+int yh_comm_describe(char* buf, uint64_t cap);
 /* All-gather of per-rank visible counts, then of the compacted draw lists (exact sizes, written at
  * prefix-sum offsets into a library-owned gathered list per frustum).  all_counts: n_ranks x n_frusta.   */
 int yh_allgather_draw_lists(yh_scene* s, uint32_t* all_counts /* may be NULL */);

@@ -174,6 +174,27 @@ def test_product_fails_loudly_without_gpu_or_library():
     assert e.value.code == _lib.YH_ERR_HIP
 
 
+def test_one_rccl_per_process_whichever_loads_first():
+    """RCCL is dlopen'ed by SONAME (yh_comm_describe says which file that was).  After `import torch` the library must
+    get torch's bundled copy - ONE RCCL in the process, the case of bench.py at N > 1 - and in the other order (the
+    library first, torch afterwards: two copies) the process must still exit cleanly."""
+    import sys
+
+    code_a = "import torch; from yume_amd import Context; print(Context.comm_describe())"
+    a = subprocess.run([sys.executable, "-c", code_a], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert a.returncode == 0, a.stderr[-500:]
+    import torch
+
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    if os.path.exists(os.path.join(torch_lib, "librccl.so")):
+        assert torch_lib in a.stdout, f"a second RCCL beside torch's: {a.stdout}"
+        v = torch.cuda.nccl.version()
+        assert f"rccl {v[0]}.{v[1]}.{v[2]} " in a.stdout, (a.stdout, v)
+    code_b = "from yume_amd import Context; print(Context.comm_describe()); import torch; print(torch.cuda.nccl.version())"
+    b = subprocess.run([sys.executable, "-c", code_b], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert b.returncode == 0 and b.stdout.startswith("rccl "), (b.returncode, b.stdout, b.stderr[-500:])
+
+
 def test_product_does_not_import_the_oracle():
     pkg = os.path.join(ROOT, "yume_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -1,6 +1,8 @@
-"""CPU tests of the N > 1 host logic: subtree-closed partitioning, shard extraction, and the all-gather of counts
-and draw lists between two gloo ranks (the compute inside a rank is the oracle here: what is under test is the
-sharding and gathering, not the kernels)."""
+"""CPU tests of the N > 1 host logic: subtree-closed partitioning, shard extraction, and the end-of-frame exchange
+between two gloo ranks in both of the library's forms - index lists (yh_allgather_draw_lists) and visibility words
+expanded by every rank (yh_allgather_draw_lists_async, the one the benchmark times) - with tests/gloo_transport.py as
+the transport.  The compute inside a rank is the oracle here: what is under test is the sharding, the id bases, the
+padding of uneven shards and the gathered order, not the kernels (those: tests/test_gpu_shards.py on one GPU)."""
 import os
 import socket
 import sys
@@ -76,6 +78,9 @@ def _rank_main(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gloo_transport
+
     from oracle import pyoracle as oracle
     from yume_amd import shard
 
@@ -89,7 +94,7 @@ def _rank_main(rank, world, port, q):
         w = oracle.frame_trs(np.ascontiguousarray(trs[:, g]), lp, llo)
         v, _ = oracle.cull(w, bounds[g], planes)
         local = [g[np.flatnonzero(v[f])].astype(np.uint32) for f in range(planes.shape[0])]
-        counts, lists = shard.allgather_draw_lists_torch(local)
+        counts, lists = gloo_transport.allgather_lists(local)
         # every rank must end up with every frustum's complete list
         world_m = oracle.frame_trs(trs, par, lo)
         vis, _ = oracle.cull(world_m, bounds, planes)
@@ -97,6 +102,21 @@ def _rank_main(rank, world, port, q):
         for f in range(planes.shape[0]):
             ok = ok and np.array_equal(np.sort(lists[f]), np.flatnonzero(vis[f]).astype(np.uint32))
             ok = ok and int(counts[:, f].sum()) == int(vis[f].sum())
+        # The words protocol, as the shards really are on N GPUs: LOCAL slots, id_base = the sizes of the ranks before,
+        # rows of the shorter shard zero-padded; the gathered list is rank-major and ascending inside a rank, and maps
+        # back through every rank's global_of_local to the unsharded visible set.
+        id_base = int(sizes[:rank].sum())
+        wcounts, wlists = gloo_transport.allgather_words(gloo_transport.pack_words(v), int(sizes[rank]), id_base)
+        g_all = np.concatenate([shard.shard_extract(par, lo, part_of, r, sizes[r])[2] for r in range(world)])  # shard-major -> global
+        ok = ok and np.array_equal(wcounts, counts)
+        for f in range(planes.shape[0]):
+            ids = wlists[f].astype(np.int64)
+            ok = ok and np.array_equal(np.sort(g_all[ids]), np.flatnonzero(vis[f]).astype(np.uint32))
+            bounds_r = np.concatenate([[0], np.cumsum(wcounts[:, f])])
+            for r in range(world):  # rank r's part: ids inside [base_r, base_r + size_r), ascending
+                part = ids[bounds_r[r]:bounds_r[r + 1]]
+                base = int(sizes[:r].sum())
+                ok = ok and bool(np.all(np.diff(part) > 0)) and (part.size == 0 or (part[0] >= base and part[-1] < base + int(sizes[r])))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -141,6 +141,7 @@ SIGNATURES = {
     "yh_scene_get_group_timings": (_int, [_vp, _vp, _vp, _u32]),
     "yh_scene_get_group_kernel_names": (_int, [_vp, _vp, _u64, C.POINTER(_u32)]),
     "yh_scene_set_grouping": (_int, [_vp, _u32]),
+    "yh_stream_probe": (_int, [_vp, _u64, _u64, _u32, C.POINTER(C.c_float)]),
     "yh_extract_planes": (None, [_vp, _vp]),
     "yh_mat4_mul": (None, [_vp, _vp, _vp]),
     "yh_perspective": (None, [C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
@@ -160,6 +161,7 @@ SIGNATURES = {
     "yh_comm_unique_id": (_int, [_vp]),
     "yh_comm_init": (_int, [_vp, _int, _int, _vp]),
     "yh_comm_destroy": (None, [_vp]),
+    "yh_comm_describe": (_int, [C.c_char_p, _u64]),
     "yh_allgather_draw_lists": (_int, [_vp, _vp]),
     "yh_get_gathered_draw_list": (_int, [_vp, _u32, _vp, _u64, C.POINTER(_u64)]),
 }

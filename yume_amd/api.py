@@ -58,12 +58,25 @@ class Context:
     def stream(self):
         return L.lib().yh_stream(self._h)
 
+    def stream_probe(self, read_bytes, write_bytes, launches=50):
+        """Mean ms per launch of a plain read + write stream over a working set of this size (measurement harness)."""
+        ms = C.c_float()
+        L.check(L.lib().yh_stream_probe(self._h, int(read_bytes), int(write_bytes), int(launches), C.byref(ms)), self._h)
+        return ms.value
+
     # ---- RCCL ----
     @staticmethod
     def comm_unique_id():
         buf = (C.c_ubyte * L.YH_UNIQUE_ID_BYTES)()
         L.check(L.lib().yh_comm_unique_id(buf))
         return bytes(buf)
+
+    @staticmethod
+    def comm_describe():
+        """Which RCCL the library resolved, e.g. 'rccl 2.22.3 from /.../librccl.so'."""
+        buf = C.create_string_buffer(640)
+        L.check(L.lib().yh_comm_describe(buf, len(buf)))
+        return buf.value.decode("utf-8", "replace")
 
     def comm_init(self, n_ranks, rank, unique_id):
         buf = (C.c_ubyte * L.YH_UNIQUE_ID_BYTES).from_buffer_copy(unique_id)

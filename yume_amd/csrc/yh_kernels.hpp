@@ -980,6 +980,21 @@ __global__ __launch_bounds__(YH_BLOCK) void k_fill_u8(uint8_t* __restrict__ p, u
     if (i < count) p[first + i] = v;
 }
 
+// Measurement harness (yh_stream_probe): the plainest read + write stream there is — 16-byte loads of nr vectors,
+// 16-byte stores of nw vectors that depend on them, one vector of each per thread and step — over buffers that stay
+// the same from launch to launch, so a working set that fits the Infinity Cache is served from it.  What a frame
+// kernel's rate on a cache-resident scene is to be compared with (bench.py: roofline.cache_ceiling).
+__global__ __launch_bounds__(YH_BLOCK) void k_stream_probe(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                           uint64_t nr, uint64_t nw) {
+    const uint64_t stride = (uint64_t)gridDim.x * YH_BLOCK;
+    const uint64_t top = nr > nw ? nr : nw;
+    for (uint64_t i = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x; i < top; i += stride) {
+        float4 v = make_float4(1.0f, 2.0f, 3.0f, 4.0f);
+        if (i < nr) v = src[i];
+        if (i < nw) dst[i] = make_float4(v.x + 1.0f, v.y, v.z, v.w);
+    }
+}
+
 // Fill plane q of a chunked array with a constant (scene creation: world = IDENTITY).
 __global__ __launch_bounds__(YH_BLOCK) void k_fill_plane(float* __restrict__ arr, uint32_t np, uint32_t q, float v,
                                                          uint64_t n) {

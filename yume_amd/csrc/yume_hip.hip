@@ -1936,6 +1936,43 @@ extern "C" int yh_scene_get_group_timings(yh_scene* s, float* mean_ms, uint32_t*
     return YH_OK;
 }
 
+// Measurement harness: a plain read + write stream over a working set of the given size (bench.py's cache ceiling).
+extern "C" int yh_stream_probe(yh_ctx* ctx, uint64_t read_bytes, uint64_t write_bytes, uint32_t launches, float* mean_ms) {
+    if (!ctx || !mean_ms || !launches) return fail(ctx, YH_ERR_BAD_ARG, "yh_stream_probe: NULL argument or no launches");
+    ARG_TRY(ctx, read_bytes + write_bytes >= 16 && read_bytes <= (64ull << 30) && write_bytes <= (64ull << 30),
+            "yh_stream_probe: sizes must be 16 bytes .. 64 GiB");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint64_t nr = read_bytes / 16, nw = write_bytes / 16, top = nr > nw ? nr : nw;
+    float4 *src = nullptr, *dst = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipSuccess;
+    if (nr) e = hipMalloc((void**)&src, nr * 16);
+    if (e == hipSuccess && nw) e = hipMalloc((void**)&dst, nw * 16);
+    if (e == hipSuccess && nr) e = hipMemsetAsync(src, 0, nr * 16, ctx->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    // every thread takes at most 4 steps: enough workgroups to fill the chip many times over at any size
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cdiv(top, YH_BLOCK * 4ull), 1), 1u << 20);
+    for (uint32_t i = 0; e == hipSuccess && i < 3 + launches; ++i) {
+        if (i == 3) e = hipEventRecord(e0, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_stream_probe, dim3(grid), dim3(YH_BLOCK), 0, ctx->stream, src, dst, nr, nw);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? YH_ERR_OOM : YH_ERR_HIP, "yh_stream_probe: %s", hipGetErrorString(e));
+    *mean_ms = ms / (float)launches;
+    return YH_OK;
+}
+
 // ------------------------------------------------------------------------------------ frustum helpers
 extern "C" void yh_mat4_mul(const float a[16], const float b[16], float out[16]) {
     M4 x, y;
@@ -2252,14 +2289,19 @@ static struct {
     fn_Broadcast Broadcast;
     fn_Group GroupStart, GroupEnd;
     fn_GetErrorString GetErrorString;
+    int version;     // ncclGetVersion: major * 10000 + minor * 100 + patch
+    char path[512];  // the file the loader resolved "librccl.so.1" to (dladdr of one of its symbols)
 } g_rccl;
 
 static int rccl_load(yh_ctx* ctx) {
     if (g_rccl.lib) return YH_OK;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // By SONAME: a process that already holds an RCCL (torch bundles one with the same SONAME) gets THAT copy again, so
+    // there is one RCCL in the process.  RTLD_LOCAL: when this library is first and torch loads its own copy later, the
+    // two must not see each other's symbols (with RTLD_GLOBAL such a process died in a double free at exit).
     void* lib = nullptr;
     for (const char* n : names)
-        if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
     if (!lib) return fail(ctx, YH_ERR_RCCL, "RCCL not found: %s", dlerror());
 #define SYM(field, name)                                                              \
     g_rccl.field = (decltype(g_rccl.field))dlsym(lib, name);                          \
@@ -2273,7 +2315,22 @@ static int rccl_load(yh_ctx* ctx) {
     SYM(GroupEnd, "ncclGroupEnd")
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+    // Which RCCL this is.  A process that has torch in it already holds torch's bundled librccl (same SONAME): the loader
+    // then hands that one out again and the process runs ONE RCCL; a second copy would show here as another path.
+    Dl_info where;
+    memset(&where, 0, sizeof where);
+    if (dladdr((void*)g_rccl.GetUniqueId, &where) && where.dli_fname) snprintf(g_rccl.path, sizeof g_rccl.path, "%s", where.dli_fname);
+    typedef int (*fn_GetVersion)(int*);
+    if (fn_GetVersion get_version = (fn_GetVersion)dlsym(lib, "ncclGetVersion")) (void)get_version(&g_rccl.version);
     g_rccl.lib = lib;
+    return YH_OK;
+}
+
+extern "C" int yh_comm_describe(char* buf, uint64_t cap) {
+    if (!buf || !cap) return fail(nullptr, YH_ERR_BAD_ARG, "yh_comm_describe: no buffer");
+    if (int rc = rccl_load(nullptr)) return rc;
+    snprintf(buf, (size_t)cap, "rccl %d.%d.%d from %s", g_rccl.version / 10000, g_rccl.version / 100 % 100, g_rccl.version % 100,
+             g_rccl.path[0] ? g_rccl.path : "(path unknown)");
     return YH_OK;
 }
 
@@ -2301,6 +2358,11 @@ extern "C" int yh_comm_init(yh_ctx* ctx, int n_ranks, int rank, const void* uniq
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     yh_nccl_id id;
     memcpy(&id, unique_id, sizeof id);
+    if (getenv("YUME_HIP_COMM_LOG")) {  // one line per rank on stderr: which RCCL, which device
+        char what[640];
+        if (yh_comm_describe(what, sizeof what) == YH_OK)
+            fprintf(stderr, "yume_hip: rank %d of %d on device %d: %s\n", rank, n_ranks, ctx->device, what);
+    }
     RCCL_TRY(ctx, g_rccl.CommInitRank(&ctx->comm, n_ranks, id, rank));
     ctx->n_ranks = n_ranks;
     ctx->rank = rank;
