@@ -293,14 +293,12 @@ def test_cfg3_five_frusta_1m(ctx, oracle):
         check_frame(oracle, s, lo, par, trs, bounds, planes)
 
 
-@pytest.mark.parametrize("tile_words,tiles_per_wg,n", [(32, 3, 1_000_000), (64, 4, 1_000_000), (256, 5, 1_000_003), (256, 1, 700_001),
-                                                         (64, 7, 5_000_000)])
-def test_expansion_knobs_give_the_same_lists(ctx, oracle, monkeypatch, tile_words, tiles_per_wg, n):
-    """The expansion's tuning knobs (words per tile, consecutive tiles per workgroup: read when a scene is created,
-    YH_TILE_WORDS / YH_EXPAND_TILES, the A/Bs of profiles/r02) change the schedule only: lists, counts and boundary
-    counts stay the oracle's.  Sizes with a ragged last tile, both the self-counting path (few tiles) and k_count's."""
+@pytest.mark.parametrize("tile_words,n", [(32, 1_000_000), (64, 1_000_000), (256, 1_000_003), (256, 700_001), (64, 5_000_000)])
+def test_expansion_knobs_give_the_same_lists(ctx, oracle, monkeypatch, tile_words, n):
+    """The expansion's tuning knob (words per tile: read when a scene is created, YH_TILE_WORDS, the A/B of
+    profiles/r02) changes the schedule only: lists, counts and boundary counts stay the oracle's.  Sizes with a ragged
+    last tile, both the self-counting path (few tiles) and k_count's."""
     monkeypatch.setenv("YH_TILE_WORDS", str(tile_words))
-    monkeypatch.setenv("YH_EXPAND_TILES", str(tiles_per_wg))
     lo, par, trs, bounds = make_scene(oracle, n, 1)
     planes = np.concatenate([oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()[1:3]])
     with gpu_scene(ctx, lo, par, trs, bounds, 3) as s:

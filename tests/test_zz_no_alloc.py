@@ -168,3 +168,43 @@ def test_frame_static_frames_replayed_from_a_hip_graph(ctx, oracle):
         finally:
             hip.hipGraphExecDestroy(gexec)
             hip.hipGraphDestroy(graph)
+
+
+def test_a_second_context_is_turned_away_while_a_static_frame_is_in_flight(ctx, oracle):
+    """All contexts of one GPU share that GPU's static array.  A second context that asks for a static frame while the
+    first one's has not been waited for gets YH_ERR_STATE (and leaves the first frame's results intact) instead of
+    racing with it; after the first context has been waited for, the second one's call goes through, and both give what
+    yh_frame gives."""
+    from yume_amd import Context, Scene, _lib
+
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    n = 300_000
+    lo = oracle.synth_level_offsets(n, 4)
+    par = oracle.synth_parents(lo)
+    other = Context(0)
+    try:
+        with Scene(ctx, n, n_levels=4, n_frusta=1) as a, Scene(other, n, n_levels=4, n_frusta=1) as b:
+            for s in (a, b):
+                s.upload_hierarchy(par, lo)
+                s.fill_synthetic()
+            a.frame(planes)
+            want = _results(a, 1)
+            ctx.wait()
+            other.wait()
+            a.frame_static(planes, _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC)  # in flight: nobody has waited for it
+            with pytest.raises(_lib.YumeHipError) as e:
+                b.frame_static(planes, _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC)
+            assert e.value.code == _lib.YH_ERR_STATE and "yh_frame_static" in str(e.value) and "another context" in str(e.value)
+            a.frame_static(planes, _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC)  # the owner itself may go on: one stream orders its calls
+            b.frame(planes)  # yh_frame is always welcome: its scratch is the scene's own
+            _same(_results(a, 1), want)  # (reading results waits for context `ctx`: the array is free again)
+            b.frame_static(planes)       # synchronous: claimed and released inside the call
+            _same(_results(b, 1), want)
+            a.frame_static(planes)
+            _same(_results(a, 1), want)
+            # errors of the static entry point name it (they used to say "yh_frame:")
+            with pytest.raises(_lib.YumeHipError) as e:
+                a.frame_static(planes, 0)
+            assert "yh_frame_static:" in str(e.value)
+    finally:
+        other.close()

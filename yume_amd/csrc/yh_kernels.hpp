@@ -62,39 +62,15 @@ __host__ __device__ __forceinline__ uint64_t eoff(uint32_t e) {
 template <bool STREAM = false>
 __device__ __forceinline__ float lde(const float* __restrict__ base, uint64_t off, int q) {
     const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off + q * 256);
-#if defined(YH_LOAD_POLICY)
-    if (STREAM) {
-        float v;
-#if YH_LOAD_POLICY == 1
-        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-#elif YH_LOAD_POLICY == 2
-        asm volatile("global_load_dword %0, %1, off sc1 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-#endif
-        return v;
-    }
-#endif
     if (STREAM) return __builtin_nontemporal_load(p);  // read-once inputs of a scene too large for the Infinity Cache
     return *p;
 }
 // World matrices are written once per frame and read back at most by the next level: streaming (nontemporal)
 // stores keep them from evicting the parents and inputs other waves still need (measured +3..5 % per frame).
-// (YH_STORE_POLICY, YH_LOAD_POLICY: experiment builds only — tools/ab_cache_policy.sh compiles the library once per
-// cache-policy variant of the streaming accesses; the default build defines neither.)
+// (Other cache policies for these accesses - plain, sc1, sc0 sc1, sc1 nt, sc0 nt, and sc1 / sc1 nt loads - were built and
+// measured in round 2: profiles/r02/ab_store_policy.txt, ab_cache_policy.txt.)
 __device__ __forceinline__ void ste(float* __restrict__ base, uint64_t off, int q, float v) {
-    float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off + q * 256);
-#if !defined(YH_STORE_POLICY)
-    __builtin_nontemporal_store(v, p);
-#elif YH_STORE_POLICY == 1
-    *p = v;
-#elif YH_STORE_POLICY == 2
-    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#elif YH_STORE_POLICY == 3
-    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-#elif YH_STORE_POLICY == 4
-    asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
-#elif YH_STORE_POLICY == 5
-    asm volatile("global_store_dword %0, %1, off sc0 nt" ::"v"(p), "v"(v) : "memory");
-#endif
+    __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off + q * 256));
 }
 template <int NP, bool STREAM = false>
 __device__ __forceinline__ void load_row(const float* __restrict__ base, uint32_t e, float (&out)[NP]) {
@@ -113,33 +89,17 @@ __device__ __forceinline__ void load_row(const float* __restrict__ base, uint32_
 // loads in between (profiles/r02/ab_store_pace.txt: s_nop 0 / 7 / 11 / 15, s_sleep 1 / 2 -> cfg5 4.510 / 4.490 /
 // 4.484 / 4.485 / 4.479 / 4.494 ms, cfg3 0.3601 / 0.3575 / 0.3569 / 0.3568 / 0.3584 / 0.3596).  Tree levels, whose
 // waves wait on their parents' rows anyway, were 0.3 % slower paced (cfg4) and stay unpaced.
-#if !defined(YH_STORE_PACE)
-#define YH_STORE_PACE 11
-#endif
 template <int Q, bool PACED>
 __device__ __forceinline__ void ste_world(float* row, float v) {
-    if (PACED) {
-#if YH_STORE_PACE >= 100
-        asm volatile("global_store_dword %0, %1, off offset:%2 sc1 nt\n\ts_sleep %3" ::"v"(row), "v"(v), "n"(Q * 256), "n"(YH_STORE_PACE - 100) : "memory");
-#else
-        asm volatile("global_store_dword %0, %1, off offset:%2 sc1 nt\n\ts_nop %3" ::"v"(row), "v"(v), "n"(Q * 256), "n"(YH_STORE_PACE) : "memory");
-#endif
-    } else {
-        asm volatile("global_store_dword %0, %1, off offset:%2 sc1 nt" ::"v"(row), "v"(v), "n"(Q * 256) : "memory");
-    }
+    if (PACED) asm volatile("global_store_dword %0, %1, off offset:%2 sc1 nt\n\ts_nop 11" ::"v"(row), "v"(v), "n"(Q * 256) : "memory");
+    else asm volatile("global_store_dword %0, %1, off offset:%2 sc1 nt" ::"v"(row), "v"(v), "n"(Q * 256) : "memory");
 }
 template <bool PACED, int... Q>
 __device__ __forceinline__ void store_world_row_impl(float* row, const float (&v)[16], std::integer_sequence<int, Q...>) {
     (ste_world<Q, PACED>(row, v[Q]), ...);
 }
-template <int NP>
-__device__ __forceinline__ void store_row(float* __restrict__ base, uint32_t e, const float (&v)[NP]);
 template <bool PACED>
 __device__ __forceinline__ void store_world_row(float* __restrict__ base, uint32_t e, const float (&v)[16]) {
-#if defined(YH_WORLD_STORES_NT_ONLY)  // experiment build: round 1's `nt` stores (tools/ab_cache_policy.sh)
-    store_row<16>(base, e, v);
-    return;
-#endif
     store_world_row_impl<PACED>(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + eoff<16>(e)), v, std::make_integer_sequence<int, 16>{});
 }
 
@@ -164,7 +124,7 @@ __device__ __forceinline__ void publish_visible(const FrameArgs& a, uint32_t chu
                                                 uint32_t vmask, uint32_t bmask) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t live = a.alive ? a.alive[chunk] : ~0ull;
-#if !defined(YH_PUBLISH_ONE_STORE)
+    // (all frusta's words in ONE store per wave, lane f keeping frustum f's: no gain at 5 frusta, profiles/r02/ab_publish.txt)
     for (uint32_t f = 0; f < a.n_frusta; ++f) {
         const uint64_t m = __ballot((vmask >> f) & 1u) & live;
         const uint64_t bm = __ballot((bmask >> f) & 1u) & live;
@@ -176,23 +136,6 @@ __device__ __forceinline__ void publish_visible(const FrameArgs& a, uint32_t chu
             if (bm) atomicAdd(&a.bcount[f], (uint32_t)__popcll(bm));
         }
     }
-#else
-    // experiment build (tools/ab_publish.sh): lane f keeps frustum f's word, ONE store of the words and one of the count
-    // bytes per wave whatever the number of frusta.  No gain at 5 frusta (cfg3 0.3594 vs 0.3581 ms): not the default.
-    uint64_t mine = 0;
-    for (uint32_t f = 0; f < a.n_frusta; ++f) {
-        const uint64_t m = __ballot((vmask >> f) & 1u) & live;
-        const uint64_t bm = __ballot((bmask >> f) & 1u) & live;
-        if (lane == f) mine = m;
-        if (bm && lane == 0) atomicAdd(&a.bcount[f], (uint32_t)__popcll(bm));
-    }
-    if (lane < a.n_frusta) {
-        uint64_t* w = &a.vismask[(uint64_t)lane * a.n_chunks + chunk];
-        const uint64_t word = merge_with_previous_launch ? (*w | mine) : mine;
-        *w = word;
-        a.viscnt[(uint64_t)lane * a.cnt_stride + chunk] = (uint8_t)__popcll(word);
-    }
-#endif
 }
 
 template <int BOUNDS>
@@ -271,7 +214,6 @@ struct ExpandArgs {
     uint64_t draw_cap;
     uint32_t n_chunks, n_tiles, id_base, self_count;
     uint32_t words;  // visibility words per tile: 32, 64 or 256
-    uint32_t tiles_per_wg; // k_expand: consecutive tiles one workgroup expands (>= 1)
     uint32_t fuse_blocks;  // k_frame_*_x: the launch's first fuse_blocks workgroups expand these (the previous frame's) words
 };
 
@@ -337,58 +279,17 @@ __device__ __forceinline__ uint32_t expand_run16(uint32_t* out /* uniform */, ui
         : "memory", "scc");
     return pos;
 }
-// The same sixteen words through LDS: a word's store above writes popcount(word) entries wherever the list has got to,
-// 166 bytes on average at cfg5 and across two or three 128-byte lines; here the entries of the sixteen words are
-// compacted into the wave's own LDS rows first, laid out as the list is relative to the 256-byte boundary below `out`,
-// and go out as whole aligned 256-byte rows (the first and the last one partial).  MEASURED SLOWER and kept as an
-// experiment build only (profiles/r02/ab_expand.txt: expansion stage cfg3 48.1 vs 39.5 us, cfg4 22.9 vs 18.3, cfg5
-// 156 vs 154): the stores were not what held the direct version back.
-#define YH_STAGE_ENTRIES (16 * 64 + 64)
-__device__ __forceinline__ uint32_t expand_run16_lds(uint32_t* out /* uniform */, uint32_t m_lo, uint32_t m_hi, uint32_t id0,
-                                                     uint32_t* stage /* this wave's YH_STAGE_ENTRIES words of LDS */) {
-    uint64_t saved;
-    uint32_t lo, hi, cnt, rank, off, id;
-    out = uniform_ptr(out);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t a = ((uint32_t)(uintptr_t)out >> 2) & 63u;  // list entries between that boundary and `out`
-    // (the low half of an LDS variable's generic address is its LDS byte offset)
-    const uint32_t pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((((uint32_t)(uintptr_t)stage) >> 2) + a);
-    uint32_t pos = pos0;
-    asm volatile(
-        "s_mov_b64 %[saved], exec\n\t"
-        YH_XW16("ds_write_b32 %[off], %[id]")
-        "s_mov_b64 exec, %[saved]\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : [saved] "=&s"(saved), [lo] "=&s"(lo), [hi] "=&s"(hi), [pos] "+s"(pos), [cnt] "=&s"(cnt),
-          [rank] "=&v"(rank), [off] "=&v"(off), [id] "=&v"(id)
-        : [mlo] "v"(m_lo), [mhi] "v"(m_hi), [id0] "v"(id0)
-        : "memory", "scc");
-    const uint32_t written = pos - pos0, total = a + written;
-    uint32_t* __restrict__ row0 = out - a;
-    for (uint32_t r = 0; r < total; r += 64u) {
-        const uint32_t i = r + lane;
-        if (i >= a && i < total) row0[i] = stage[i];
-    }
-    return written;
-}
+// (The same through LDS - a wave's entries compacted into its own LDS rows and written as whole aligned 256-byte rows -
+// was measured slower: profiles/r02/ab_expand.txt, expansion stage cfg3 48.1 vs 39.5 us, cfg4 22.9 vs 18.3.)
 #undef YH_XW16
 #undef YH_XW
-#if defined(YH_EXPAND_LDS)  // experiment build (tools/ab_expand.sh): rows staged in LDS
-#define YH_EXPAND_STAGE_WORDS YH_STAGE_ENTRIES
-#else
-#define YH_EXPAND_STAGE_WORDS 1
-#endif
 // A run of n_words <= 64 words: groups of sixteen, the masks rotated down by sixteen lanes between groups.
 __device__ __forceinline__ void expand_run(uint32_t* out /* uniform: the run's first list entry */, uint32_t m_lo, uint32_t m_hi,
-                                           uint32_t n_words /* uniform */, uint32_t id0, uint32_t* stage) {
+                                           uint32_t n_words /* uniform */, uint32_t id0) {
     const uint32_t src = (((threadIdx.x & 63u) + 16u) & 63u) << 2;
     n_words = __builtin_amdgcn_readfirstlane(n_words);
     for (uint32_t g = 0;;) {
-#if defined(YH_EXPAND_LDS)
-        const uint32_t written = expand_run16_lds(out, m_lo, m_hi, id0, stage);
-#else
         const uint32_t written = expand_run16(out, m_lo, m_hi, id0);
-#endif
         g += 16u;
         if (g >= n_words) break;
         out += written;
@@ -398,25 +299,23 @@ __device__ __forceinline__ void expand_run(uint32_t* out /* uniform: the run's f
     }
 }
 
-// Expansion of tiles [t0, t1) of visibility words into their stretch of the ordered list.  Every wave owns a CONTIGUOUS
-// run of a tile's words: lane l loads word l of the run (one coalesced load), the run's words then come back one at a
+// Expansion of tile t of frustum f's visibility words into its stretch of the ordered list.  Every wave owns a CONTIGUOUS
+// run of the tile's words: lane l loads word l of the run (one coalesced load), the run's words then come back one at a
 // time as wave-uniform values (v_readlane), so the running output position lives on the scalar unit (expand_run).
 // Larger tiles are faster (profiles/r02/ab_tile_words.txt: the stage's time is ~1.3 ns x workgroups + the time of the
-// words), which suggested giving a workgroup several consecutive tiles - the base carried from tile to tile, the next
-// tile's words loaded before this tile's are expanded.  The loop is here and tested, the host asks for ONE tile: two
-// to sixteen measured equal or slower at every size (profiles/r02/ab_expand_tiles_per_wg.txt).
-__device__ __forceinline__ void expand_tiles(const ExpandArgs& x, const uint32_t t0, const uint32_t t1, const uint32_t f) {
+// words); several consecutive tiles per workgroup - base carried along, the next tile's words prefetched - measured
+// equal or slower at every size (profiles/r02/ab_expand_tiles_per_wg.txt) and is gone: one tile per workgroup.
+__device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t t, const uint32_t f) {
     __shared__ uint32_t s_red[4];
-    __shared__ uint32_t s_wave[2][4];
-    __shared__ uint32_t s_stage[4][YH_EXPAND_STAGE_WORDS];
+    __shared__ uint32_t s_wave[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t* __restrict__ masks = x.vismask + (uint64_t)f * x.n_chunks;
-    const uint32_t c0 = t0 * x.words;
-    const uint32_t wpw = x.words >> 2;      // words per wave: 8, 16 or 64
-    uint32_t cw = c0 + wv * wpw;            // first word of this wave's run
-    uint64_t m = (lane < wpw && cw + lane < x.n_chunks) ? masks[cw + lane] : 0ull;
-    // base = visible entities in the tiles before the first one
+    const uint32_t c0 = t * x.words;
+    const uint32_t wpw = x.words >> 2;       // words per wave: 8, 16 or 64
+    const uint32_t cw = c0 + wv * wpw;       // first word of this wave's run
+    const uint64_t m = (lane < wpw && cw + lane < x.n_chunks) ? masks[cw + lane] : 0ull;
+    // base = visible entities in the tiles before this one
     uint32_t part = 0;
     if (x.self_count) {  // 16 byte-counts per load; c0 is a multiple of 32
         const uint4* __restrict__ c16 = reinterpret_cast<const uint4*>(x.viscnt + (uint64_t)f * x.cnt_stride);
@@ -432,56 +331,46 @@ __device__ __forceinline__ void expand_tiles(const ExpandArgs& x, const uint32_t
         for (uint32_t i = tid; i < (c0 >> YH_SEG_SHIFT); i += YH_BLOCK) part += seg[i];
     }
     uint32_t base = block_sum_256(part, s_red);
-    if (!x.self_count) base += x.tilecnt[(uint64_t)f * x.tc_stride + t0];
+    if (!x.self_count) base += x.tilecnt[(uint64_t)f * x.tc_stride + t];
     // (entity counts stay below 2^31: positions and the capacity compare in 32 bits)
     const uint32_t cap = x.draw_cap > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)x.draw_cap;
     uint32_t* __restrict__ out = x.draw[f];
-    for (uint32_t t = t0; t < t1; ++t, cw += x.words) {
-        // the next tile's words, on their way while this tile is expanded
-        const uint32_t cn = cw + x.words;
-        const uint64_t m_next = (t + 1 < t1 && lane < wpw && cn + lane < x.n_chunks) ? masks[cn + lane] : 0ull;
-        // visible entities of each wave's run
-        uint32_t run = (uint32_t)__popcll(m);
+    // visible entities of each wave's run
+    uint32_t run = (uint32_t)__popcll(m);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) run += __shfl_xor(run, o);
-        run = __builtin_amdgcn_readfirstlane(run);  // the same in every lane: say so, the branches below are then scalar
-        uint32_t* sw = s_wave[(t - t0) & 1u];  // two sets: a wave may write tile t + 1's while another still reads tile t's
-        if (lane == 0) sw[wv] = run;
-        __syncthreads();
-        uint32_t before = 0;
-        for (uint32_t w = 0; w < wv; ++w) before += sw[w];
-        const uint32_t own = sw[0] + sw[1] + sw[2] + sw[3];
-        if (tid == 0) {
-            if (t == 0 && f == 0)  // all of them: the frame that uses this set next may cull more frusta than this one
-                for (uint32_t q = 0; q < YH_K_MAX_FRUSTA; ++q) x.bcount_next[q] = 0;
-            if (t + 1 == x.n_tiles) {  // totals of this frustum, to the device (all-gather) and straight to the host
-                x.counts[f] = base + own;
-                x.host_counts[f] = base + own;
-                x.host_counts[YH_K_MAX_FRUSTA + f] = x.bcount_cur[f];
-            }
+    for (int o = 32; o > 0; o >>= 1) run += __shfl_xor(run, o);
+    run = __builtin_amdgcn_readfirstlane(run);  // the same in every lane: say so, the branches below are then scalar
+    if (lane == 0) s_wave[wv] = run;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wv; ++w) before += s_wave[w];
+    const uint32_t own = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (tid == 0) {
+        if (t == 0 && f == 0)  // all of them: the frame that uses this set next may cull more frusta than this one
+            for (uint32_t q = 0; q < YH_K_MAX_FRUSTA; ++q) x.bcount_next[q] = 0;
+        if (t + 1 == x.n_tiles) {  // totals of this frustum, to the device (all-gather) and straight to the host
+            x.counts[f] = base + own;
+            x.host_counts[f] = base + own;
+            x.host_counts[YH_K_MAX_FRUSTA + f] = x.bcount_cur[f];
         }
-        const uint32_t n_words = min(wpw, x.n_chunks > cw ? x.n_chunks - cw : 0u);
-        if (run != 0 && n_words != 0) {  // (wave-uniform after the reduction)
-            uint32_t pos = __builtin_amdgcn_readfirstlane(base + before);  // scalar: list position of the run's next entry
-            const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
-            const uint32_t id0 = (cw << 6) + lane + x.id_base;
-            if (pos + run <= cap) {  // the whole run fits the list: the issue-lean loop
-                expand_run(out + pos, m_lo, m_hi, n_words, id0, s_stage[wv]);
-            } else {
-                for (uint32_t i = 0; i < n_words; ++i) {  // the list overflows inside this run: every lane checks its own entry
-                    const uint32_t lo = __builtin_amdgcn_readlane(m_lo, i), hi = __builtin_amdgcn_readlane(m_hi, i);
-                    const uint64_t word = ((uint64_t)hi << 32) | lo;
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-                    if (((word >> lane) & 1ull) && pos + rank < cap) out[pos + rank] = id0 + (i << 6);
-                    pos += (uint32_t)__popcll(word);
-                }
-            }
-        }
-        base += own;
-        m = m_next;
+    }
+    const uint32_t n_words = min(wpw, x.n_chunks > cw ? x.n_chunks - cw : 0u);
+    if (run == 0 || n_words == 0) return;  // (wave-uniform after the reduction)
+    uint32_t pos = __builtin_amdgcn_readfirstlane(base + before);  // scalar: list position of the run's next entry
+    const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
+    const uint32_t id0 = (cw << 6) + lane + x.id_base;
+    if (pos + run <= cap) {  // the whole run fits the list: the issue-lean loop
+        expand_run(out + pos, m_lo, m_hi, n_words, id0);
+        return;
+    }
+    for (uint32_t i = 0; i < n_words; ++i) {  // the list overflows inside this run: every lane checks its own entry
+        const uint32_t lo = __builtin_amdgcn_readlane(m_lo, i), hi = __builtin_amdgcn_readlane(m_hi, i);
+        const uint64_t word = ((uint64_t)hi << 32) | lo;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+        if (((word >> lane) & 1ull) && pos + rank < cap) out[pos + rank] = id0 + (i << 6);
+        pos += (uint32_t)__popcll(word);
     }
 }
-__device__ __forceinline__ void expand_tile(const ExpandArgs& x, const uint32_t t, const uint32_t f) { expand_tiles(x, t, t + 1u, f); }
 
 
 // ---------------------------------------------------------------------------------------------------
@@ -902,11 +791,8 @@ __global__ __launch_bounds__(YH_BLOCK) void k_count(const ExpandArgs x) {
     if (tid == YH_BLOCK - 1) row[x.n_tiles + seg] = excl + c;
 }
 
-// grid = (ceil(n_tiles / tiles_per_wg), frusta)
-__global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) {
-    const uint32_t t0 = blockIdx.x * x.tiles_per_wg;
-    expand_tiles(x, t0, min(t0 + x.tiles_per_wg, x.n_tiles), blockIdx.y);
-}
+// grid = (n_tiles, frusta)
+__global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) { expand_tile(x, blockIdx.x, blockIdx.y); }
 
 // The same sweep when changes are tracked (yh_scene_track_changes): one wave per 64-entity chunk first publishes two
 // ballots as the chunk's words of the two change masks, then clears both flags.
@@ -1121,7 +1007,6 @@ __global__ __launch_bounds__(YH_BLOCK) void k_gather_count(const GatherArgs g) {
 __global__ __launch_bounds__(YH_BLOCK) void k_gather_expand(const GatherArgs g) {
     __shared__ uint32_t s_red[4];
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_stage[4][YH_EXPAND_STAGE_WORDS];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t t = blockIdx.x, f = blockIdx.y, r = blockIdx.z;
@@ -1148,7 +1033,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_gather_expand(const GatherArgs g) 
     const uint32_t n_words = min(wpw, g.words > cw ? g.words - cw : 0u);
     if (n_words == 0) return;
     const uint32_t pos = __builtin_amdgcn_readfirstlane(base + before);
-    expand_run(g.out[f] + pos, (uint32_t)m, (uint32_t)(m >> 32), n_words, (cw << 6) + lane + g.peer[r * 4 + 1], s_stage[wv]);
+    expand_run(g.out[f] + pos, (uint32_t)m, (uint32_t)(m >> 32), n_words, (cw << 6) + lane + g.peer[r * 4 + 1]);
 }
 
 // ---------------------------------------------------------------------------------------------------

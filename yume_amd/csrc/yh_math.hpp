@@ -18,26 +18,9 @@ struct M4 {
 // A.k[r]*B.c.z + A.t[r]*B.c.w, left to right.  Affine structure is deliberately not exploited.
 YH_HD M4 m4_mul(const M4& a, const M4& b) {
     M4 r;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(YH_PK_MUL)
-    // EXPERIMENT (off; profiles/r02/ab_pk_mul.txt): two rows of a column per packed instruction (v_pk_mul_f32 /
-    // v_pk_add_f32: the same IEEE products and sums in the same order, two at a time; all parity tests pass).  18 % fewer
-    // vector instructions in k_frame_chain<3>, but 92 VGPRs instead of 75: with the 80-VGPR cap it spills (cfg2 +45 %),
-    // without it (5 waves) cfg2 is 1.5 % and cfg5 1.4 % slower.  The kernels wait for memory, not for the vector unit.
-    typedef float f2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const f2 bx = b.v[c * 4 + 0], by = b.v[c * 4 + 1], bz = b.v[c * 4 + 2], bw = b.v[c * 4 + 3];
-#pragma unroll
-        for (int h = 0; h < 4; h += 2) {
-            const f2 a0 = {a.v[0 + h], a.v[1 + h]}, a1 = {a.v[4 + h], a.v[5 + h]}, a2 = {a.v[8 + h], a.v[9 + h]},
-                     a3 = {a.v[12 + h], a.v[13 + h]};
-            const f2 s = a0 * bx + a1 * by + a2 * bz + a3 * bw;
-            r.v[c * 4 + h] = s.x;
-            r.v[c * 4 + h + 1] = s.y;
-        }
-    }
-    return r;
-#endif
+    // (two rows of a column per packed instruction - v_pk_mul_f32 / v_pk_add_f32, the same IEEE results - saves 18 % of the
+    // vector instructions of k_frame_chain<3> and costs 17 VGPRs: spills or an occupancy step, 1.5 % slower either way;
+    // profiles/r02/ab_pk_mul.txt.  The kernels wait for memory, not for the vector unit.)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float bx = b.v[c * 4 + 0], by = b.v[c * 4 + 1], bz = b.v[c * 4 + 2], bw = b.v[c * 4 + 3];

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <new>
 #include <string>
 #include <vector>
@@ -82,7 +83,6 @@ struct yh_scene {
     uint8_t* chg_cnt = nullptr;       // the same for the change mask
     uint64_t vis_bytes = 0;           // bytes of the counts allocation (zeroed once at creation)
     uint32_t n_chunks = 0, n_tiles = 0, tile_words = 64;
-    uint32_t expand_tiles = 0;        // 0: expand_tiles_per_wg decides
     uint32_t n_segs = 0;              // k_count segments (4096 words each); tile-count rows hold n_tiles + n_segs words
     uint32_t* h_counts = nullptr;     // host-mapped: written by k_expand ([f] totals, [8+f] boundary counts)
     uint32_t* h_counts_dev = nullptr; // device address of h_counts
@@ -190,6 +190,19 @@ static int flush_expand(yh_scene* s);
 // that device current) and everything afterwards uses yh_ctx::scratch_ptr.
 static __device__ __align__(256) unsigned char scratch[YH_STATIC_SCRATCH_BYTES];
 
+// Who is using a GPU's copy of `scratch`: the context whose yh_frame_static has not been waited for yet (NULL: nobody).
+// Two contexts of one GPU share the array; a second one that would write it while the first one's frame may still be
+// running is turned away (YH_ERR_STATE) instead of corrupting both frames' lists.  Claimed by yh_frame_static, released
+// when the owner's stream has been synchronised through the library (yh_wait, any yh_get_ / yh_download_ call, a frame
+// without YH_FRAME_ASYNC) or the context is shut down.  Work the caller replays itself (a captured graph launched on
+// yh_stream) is beyond the library's sight: its ordering stays the caller's business, as the header says.
+#define YH_MAX_DEVICES 64
+static std::atomic<yh_ctx*> g_static_owner[YH_MAX_DEVICES];
+static void release_static(yh_ctx* ctx) {
+    yh_ctx* me = ctx;
+    if (ctx && ctx->device >= 0) g_static_owner[ctx->device % YH_MAX_DEVICES].compare_exchange_strong(me, nullptr);
+}
+
 static thread_local std::string g_err;
 
 static int fail(yh_ctx* ctx, int code, const char* fmt, ...) {
@@ -241,8 +254,6 @@ extern "C" int yh_init(int device_id, yh_ctx** out) {
     // shared queue holds back everything behind it (a gather stream created after RCCL's own landed on the frames'
     // queue and serialised the exchange with the frames: 50 -> 69 us per cfg2 frame).
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipGetSymbolAddress((void**)&c->scratch_ptr, HIP_SYMBOL(scratch));  // device `device_id` is current
-    if (e == hipSuccess && !c->scratch_ptr) e = hipErrorInvalidSymbol;
     for (hipStream_t st : {c->stream, c->stream_c}) {
         hipEvent_t touch = nullptr;
         if (e == hipSuccess) e = hipEventCreateWithFlags(&touch, hipEventDisableTiming);
@@ -263,6 +274,14 @@ extern "C" int yh_init(int device_id, yh_ctx** out) {
         return fail(nullptr, YH_ERR_UNSUPPORTED, "yh_init: device is %s; this library is built for gfx950 only",
                     arch.c_str());
     }
+    // the code object exists for gfx950 only: the symbol is looked up after the architecture is known to be that
+    e = hipGetSymbolAddress((void**)&c->scratch_ptr, HIP_SYMBOL(scratch));  // device `device_id` is current
+    if (e == hipSuccess && !c->scratch_ptr) e = hipErrorInvalidSymbol;
+    if (e != hipSuccess) {
+        for (hipStream_t st : {c->stream_c, c->stream}) (void)hipStreamDestroy(st);
+        delete c;
+        return fail(nullptr, YH_ERR_HIP, "yh_init: the static scratch array could not be resolved: %s", hipGetErrorString(e));
+    }
     *out = c;
     return YH_OK;
 }
@@ -278,6 +297,7 @@ extern "C" void yh_shutdown(yh_ctx* ctx) {
         (void)hipStreamSynchronize(st);
         (void)hipStreamDestroy(st);
     }
+    release_static(ctx);
     delete ctx;
 }
 
@@ -301,6 +321,7 @@ extern "C" int yh_wait(yh_ctx* ctx) {
         if (int rc = flush_expand(s)) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->stream_c) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_c));
+    release_static(ctx);
     return YH_OK;
 }
 
@@ -469,7 +490,6 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
     if (const char* v = getenv("YH_LDS_PARENTS")) s->lds_parents = v[0] == '1';
     if (const char* v = getenv("YH_BIG_TREE")) s->big_tree = strtoull(v, nullptr, 10);
     if (const char* v = getenv("YH_BIG_FLAT")) s->big_flat = strtoull(v, nullptr, 10);
-    if (const char* v = getenv("YH_EXPAND_TILES")) s->expand_tiles = (uint32_t)strtoul(v, nullptr, 10);
     if (const char* v = getenv("YH_DEFER_FIRST_MAX")) s->defer_first_max = (uint32_t)strtoul(v, nullptr, 10);
     ctx->scenes.push_back(s);
     *out = s;
@@ -494,7 +514,7 @@ static int flush_expand(yh_scene* s) {
         s->pend_count = false;
         hipLaunchKernelGGL(k_count, dim3(s->n_segs, s->pend_frusta), dim3(YH_BLOCK), 0, s->ctx->stream, s->pend);
     }
-    hipLaunchKernelGGL(k_expand, dim3(cdiv(s->pend.n_tiles, s->pend.tiles_per_wg), s->pend_frusta), dim3(YH_BLOCK), 0, s->ctx->stream, s->pend);
+    hipLaunchKernelGGL(k_expand, dim3(s->pend.n_tiles, s->pend_frusta), dim3(YH_BLOCK), 0, s->ctx->stream, s->pend);
     HIP_TRY(s->ctx, hipGetLastError());
     return YH_OK;
 }
@@ -504,6 +524,7 @@ static int sync_scene(yh_scene* s) {
     HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
     if (s->ctx->stream_c) HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream_c));
     s->frame_pending = false;
+    release_static(s->ctx);
     return YH_OK;
 }
 
@@ -1313,10 +1334,6 @@ static void build_cull_plan(const float* planes, uint32_t n_frusta, CullPlan& pl
     plan.n_normals = n_groups;
 }
 
-// Consecutive tiles one k_expand workgroup takes (base carried from tile to tile, the next tile's words loaded ahead).
-// One: more did not pay at any size (profiles/r02/ab_expand_tiles_per_wg.txt: cfg3's stage 41.6 / 39.3 / 42.3 / 49.5 us
-// with 1 / 2 / 4 / 8 tiles, cfg5's 157 / 159 / 168 / 173, cfg4's 18.6 / 20.0 / 26.8 / 38.7).  A/B: env YH_EXPAND_TILES.
-static uint32_t expand_tiles_per_wg(const yh_scene* s, uint32_t) { return s->expand_tiles ? s->expand_tiles : 1u; }
 
 // Where the stage-3 scratch of one frame lies inside the static array (yh_frame_static): 32 counter words (only
 // [8, 24) are used: the boundary counters and the set k_expand zeroes), tile counts, visibility words, byte counts.
@@ -1338,16 +1355,16 @@ static StaticLayout static_layout(const yh_scene* s, uint32_t n_frusta) {
 static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint32_t flags, const bool use_static, const char* who) {
     if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "%s: scene is NULL", who);
     yh_ctx* ctx = s->ctx;
-    if (!s->have_hierarchy) return fail(ctx, YH_ERR_STATE, "yh_frame: call yh_upload_hierarchy first");
+    if (!s->have_hierarchy) return fail(ctx, YH_ERR_STATE, "%s: call yh_upload_hierarchy first", who);
     const bool cull = !(flags & YH_FRAME_NO_CULL) && s->desc.bounds_kind != YH_BOUNDS_NONE && n_frusta > 0;
     if (cull) {
-        ARG_TRY(ctx, planes, "yh_frame: planes is NULL");
-        ARG_TRY(ctx, n_frusta <= s->desc.n_frusta, "yh_frame: n_frusta exceeds the scene's draw lists");
+        if (!planes) return fail(ctx, YH_ERR_BAD_ARG, "%s: planes is NULL", who);
+        if (n_frusta > s->desc.n_frusta) return fail(ctx, YH_ERR_BAD_ARG, "%s: n_frusta exceeds the scene's draw lists", who);
         if (s->desc.bounds_kind == YH_BOUNDS_MESH_TABLE && s->n_meshes == 0)
-            return fail(ctx, YH_ERR_STATE, "yh_frame: mesh table not uploaded");
+            return fail(ctx, YH_ERR_STATE, "%s: mesh table not uploaded", who);
     }
     if (s->desc.local_kind == YH_LOCAL_TRS && !(flags & YH_FRAME_ALL_DIRTY))
-        return fail(ctx, YH_ERR_UNSUPPORTED, "yh_frame: TRS scenes recompute every entity; pass YH_FRAME_ALL_DIRTY");
+        return fail(ctx, YH_ERR_UNSUPPORTED, "%s: TRS scenes recompute every entity; pass YH_FRAME_ALL_DIRTY", who);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     if (s->exp_pending && s->pend_demand)  // nobody read the lists of a YH_FRAME_LISTS_ON_DEMAND frame: dropped unexpanded
@@ -1362,6 +1379,13 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
                         "%s: %llu entities x %u frusta need %llu bytes of stage-3 scratch, the static array holds %llu "
                         "(about 119M entity-frusta); use yh_frame",
                         who, (unsigned long long)s->n, n_frusta, (unsigned long long)sl.bytes, (unsigned long long)YH_STATIC_SCRATCH_BYTES);
+        if (cull) {  // this GPU's array is one: another context's static frame that nobody has waited for still owns it
+            yh_ctx* owner = nullptr;
+            if (!g_static_owner[ctx->device % YH_MAX_DEVICES].compare_exchange_strong(owner, ctx) && owner != ctx)
+                return fail(ctx, YH_ERR_STATE,
+                            "%s: another context on device %d has a static frame in flight (its stage-3 scratch is this GPU's one "
+                            "static array); wait for that context (yh_wait) first, or use yh_frame", who, ctx->device);
+        }
         if (int rc = flush_expand(s)) return rc;  // an expansion a deferred frame left behind: launch it now (no allocation)
         // the array keeps the previous call's contents: the boundary counters must start at zero, everything else
         // (tile counts, words, byte counts) is fully rewritten by this frame's launches before it is read
@@ -1569,8 +1593,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
             c.words = s->tile_words;
             c.self_count = (s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES && s->tile_words <= 64u);
             if (!c.self_count) hipLaunchKernelGGL(k_count, dim3(s->n_segs, 2), dim3(YH_BLOCK), 0, st, c);
-            c.tiles_per_wg = expand_tiles_per_wg(s, 2);
-            hipLaunchKernelGGL(k_expand, dim3(cdiv(s->n_tiles, c.tiles_per_wg), 2), dim3(YH_BLOCK), 0, st, c);
+            hipLaunchKernelGGL(k_expand, dim3(s->n_tiles, 2), dim3(YH_BLOCK), 0, st, c);
             HIP_TRY(ctx, hipGetLastError());
             s->chg_valid = true;
             launches += c.self_count ? 2 : 3;
@@ -1616,7 +1639,6 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
         x.words = s->tile_words;
         x.id_base = s->desc.id_base;
         x.self_count = (s->n_tiles <= (uint32_t)YH_SELF_COUNT_TILES && s->tile_words <= 64u);
-        x.tiles_per_wg = expand_tiles_per_wg(s, n_frusta);
         // Lists on demand (frames whose words go to the gather, which expands this GPU's part along with the others'):
         // neither tile bases nor lists unless somebody asks before the next frame; what k_expand does on the side - the
         // boundary counters of the frame after next start at zero - is done by a one-wave kernel.
@@ -1657,7 +1679,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
             s->pend_frusta = n_frusta;
             s->exp_pending = true;
         } else {
-            hipLaunchKernelGGL(k_expand, dim3(cdiv(s->n_tiles, x.tiles_per_wg), n_frusta), dim3(YH_BLOCK), 0, st, x);
+            hipLaunchKernelGGL(k_expand, dim3(s->n_tiles, n_frusta), dim3(YH_BLOCK), 0, st, x);
             HIP_TRY(ctx, hipGetLastError());
             ++launches;
         }
