@@ -254,15 +254,17 @@ int yh_build_object_data(yh_scene* s, uint32_t frustum, uint32_t batch_offset);
 int yh_get_object_data(yh_scene* s, uint32_t frustum, void* model_matrices, yh_draw_cmd* cmds, uint64_t cap,
                        uint64_t* written);
 void* yh_object_data_device(yh_scene* s, uint32_t frustum, void** cmds_device);
-/* Per-mesh bucketing (mesh-table scenes, n_meshes <= 256).  The reference's draw loop rebinds the
+/* Per-mesh bucketing (mesh-table scenes, n_meshes <= 65536: up to 256 keys the tiles of the list are
+ * sorted inside LDS, beyond that every wave owns a slice of the list and the counters live in device memory).  The reference's draw loop rebinds the
  * vertex buffer whenever the mesh differs from the previous object's (RenderApi.zig:1434; the pipeline likewise when
  * the material does, :1411): yh_build_mesh_buckets orders the frustum's visible entities by mesh id — ascending
  * mesh, ascending entity inside a mesh (a stable counting sort of the draw list, on the device) — so that loop binds
  * each mesh once.  Object data and draw records (yh_get_object_data / yh_object_data_device) are then in bucket
  * order, record i still {vertices_count, 1, 0, batch_offset + i} (simple.vert:29 indexes objects by gl_BaseInstance,
  * so one record per object stays), and bucket m = {m, first, count} says which records [first, first + count) draw
- * mesh m: one vkCmdDrawIndirect(count, stride 16) per bound mesh.  A host that wants material buckets too gives each
- * (material, mesh) pair its own mesh-table entry.  yh_get_mesh_buckets: buckets (n_meshes entries) and the
+ * mesh m: one vkCmdDrawIndirect(count, stride 16) per bound mesh.  Material buckets (the pipeline rebinding rule,
+ * RenderApi.zig:1411): a key is a mesh-table ENTRY, so a host gives each (material, mesh) pair its own entry, ordered
+ * by material first - GpuTransformCullSystem_setMaterialComponent does exactly that from the ECS.  yh_get_mesh_buckets: buckets (n_meshes entries) and the
  * bucket-ordered global entity ids; either may be NULL.                                                            */
 typedef struct yh_bucket {
     uint32_t mesh, first, count;

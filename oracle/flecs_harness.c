@@ -31,6 +31,7 @@
  *              a child of entity index bits(m[0]), with its local matrix (and bounds) from the scene's arrays
  *              (GameApp.zig:204-215: new(), setParent, set LocalTransform)
  *              kind 7: world.enable(entity, bits(m[0]) != 0) (ecs.zig:546)
+ *              kind 8: the entity's Material := material bits(m[0]) (GPU build with YFH_MATERIALS=1)
  * out.bin:   per frame: world rows n x 68 B, local rows n x 68 B (all zero for deleted entities), u64 batches,
  *            u64 rows_seen, u32 up_fields_shared; GPU build + YFH2: then per frustum u32 count, u32 entity_index[count]
  *            (GPU build: batches = slot-order rebuilds so far, rows_seen = entities in the device scene), then
@@ -44,6 +45,10 @@
  *            (camera 0 perspective 75 deg / 0.1 / 200, camera 1 orthographic) with all three matrices zero, and the system
  *            derives this frame's matrices itself (setCameraPipeline, aspect 2); after `patches` every frame then writes
  *            per camera f32 view[16], projection[16], view_projection[16] as the component holds them.
+ *            YFH_MATERIALS=1 (implies YFH_ECS_INPUTS): every entity with a mesh also gets a Material{ref} component,
+ *            material (e / 4) % 3 of three; after the above every frame writes frustum 0's draw buckets
+ *            (GpuTransformCullSystem_drawBuckets): u32 n_buckets, per bucket u32 material, mesh (indices), first, count,
+ *            then u64 n_records and u32 entity_index[n_records] in record order.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -207,7 +212,10 @@ int main(int argc, char** argv) {
     } FakeMesh;
     static FakeMesh fake_meshes[3];
     const char* cam_pipeline = getenv("YFH_CAMERA_PIPELINE");
-    const int ecs_inputs = getenv("YFH_ECS_INPUTS") != NULL || cam_pipeline != NULL;
+    const int with_materials = getenv("YFH_MATERIALS") != NULL;
+    const int ecs_inputs = getenv("YFH_ECS_INPUTS") != NULL || cam_pipeline != NULL || with_materials;
+    static uint8_t fake_materials[3][64]; /* stand-ins for shading.Material: only their addresses matter */
+    ecs_entity_t material_id = 0;
     ecs_entity_t camera_id = 0, mesh_id = 0, cams[2] = {0, 0};
     if (ecs_inputs) {
         ecs_entity_desc_t ed = {0};
@@ -233,10 +241,24 @@ int main(int argc, char** argv) {
             const float b[6] = {-0.5f * k, -0.25f * k - 0.5f, -1.0f, 0.5f * k, 0.25f * k + 0.5f, 1.5f};
             memcpy(m->bounds, b, sizeof b);
         }
+        if (with_materials) {
+            ecs_entity_desc_t ed3 = {0};
+            ed3.use_low_id = true;
+            ed3.name = "Material";
+            ecs_component_desc_t cd3 = {0};
+            cd3.entity = ecs_entity_init(w, &ed3);
+            cd3.type.size = 8;
+            cd3.type.alignment = 8;
+            material_id = ecs_component_init(w, &cd3);
+        }
         for (uint32_t e = 0; e < n; ++e)
             if (e % 4 && ent[e]) {
                 const FakeMesh* ref = &fake_meshes[e % 4 - 1];
                 ecs_set_id(w, ent[e], mesh_id, sizeof ref, &ref);
+                if (with_materials) {
+                    const void* mat = fake_materials[(e / 4) % 3];
+                    ecs_set_id(w, ent[e], material_id, sizeof mat, &mat);
+                }
             }
         uint8_t cam[240];
         if (cam_pipeline) { /* cameras ON scene entities, matrices left for the system to derive */
@@ -283,6 +305,7 @@ int main(int argc, char** argv) {
         if (GpuTransformCullSystem_setCameraComponent(gpu, camera_id, 176) != YH_OK ||
             GpuTransformCullSystem_setMeshComponent(gpu, mesh_id, 32, 16) != YH_OK)
             return 3;
+        if (with_materials && GpuTransformCullSystem_setMaterialComponent(gpu, material_id) != YH_OK) return 3;
         if (cam_pipeline) { /* @offsetOf of opts.kind, opts.data, view, projection, view_projection (camera.zig:42-66) */
             const GpuCameraLayout layout = {0, 4, 48, 112, 176};
             if (GpuTransformCullSystem_setCameraPipeline(gpu, &layout, 2.0f) != YH_OK) return 3;
@@ -333,6 +356,10 @@ int main(int argc, char** argv) {
                 if (ecs_inputs && e % 4) {
                     const FakeMesh* ref = &fake_meshes[e % 4 - 1];
                     ecs_set_id(w, ent[e], mesh_id, sizeof ref, &ref);
+                    if (with_materials) {
+                        const void* mat = fake_materials[(e / 4) % 3];
+                        ecs_set_id(w, ent[e], material_id, sizeof mat, &mat);
+                    }
                 } else if (!ecs_inputs && v2) {
                     GpuTransformCullSystem_setBounds(gpu, ent[e], bounds + 6 * (size_t)e);
                 }
@@ -354,6 +381,17 @@ int main(int argc, char** argv) {
                 uint32_t on;
                 memcpy(&on, m, 4);
                 ecs_enable(w, target, on != 0);
+                continue;
+            }
+            if (kind == 8) {
+#ifdef USE_GPU_SYSTEM
+                if (with_materials) {
+                    uint32_t k;
+                    memcpy(&k, m, 4);
+                    const void* mat = fake_materials[k % 3];
+                    ecs_set_id(w, target, material_id, sizeof mat, &mat);
+                }
+#endif
                 continue;
             }
             if (kind == 4 || kind == 5) { /* cull inputs held by the ECS: GPU build with YFH_ECS_INPUTS only */
@@ -464,6 +502,26 @@ int main(int argc, char** argv) {
                 fwrite(cam + 48, 64, 3, fout);
                 if (GpuTransformCullSystem_frustumCamera(gpu, (uint32_t)k) != cams[k]) return 6; /* query order = creation order here */
             }
+        if (with_materials) {
+            static GpuDrawBucket bk[64];
+            uint32_t nb = 0;
+            uint64_t nrec = 0;
+            if (GpuTransformCullSystem_drawBuckets(gpu, 0, 0, bk, 64, &nb, vis, n, &nrec) != YH_OK) {
+                fprintf(stderr, "flecs_gpu_harness: drawBuckets: %s\n", yh_last_error(ctx));
+                return 7;
+            }
+            fwrite(&nb, 4, 1, fout);
+            for (uint32_t k = 0; k < nb; ++k) {
+                const uint32_t rec[4] = {bk[k].material ? (uint32_t)(((const uint8_t*)bk[k].material - &fake_materials[0][0]) / 64) : 0xFFFFFFFFu,
+                                         (uint32_t)((const FakeMesh*)bk[k].mesh - fake_meshes), bk[k].first, bk[k].count};
+                fwrite(rec, 4, 4, fout);
+            }
+            fwrite(&nrec, 8, 1, fout);
+            for (uint32_t e = 0; e < n; ++e)
+                if (ent[e]) idx_of_id[(uint32_t)ent[e]] = e;
+            for (uint64_t i = 0; i < nrec; ++i) vis_idx[i] = idx_of_id[(uint32_t)vis[i]];
+            fwrite(vis_idx, 4, nrec, fout);
+        }
 #endif
     }
 #ifdef USE_GPU_SYSTEM

@@ -42,7 +42,7 @@ def write_scene(path, lo, parent, local_m, root_m, planes, bounds, frames):
                 f.write(np.ascontiguousarray(m, np.float32).tobytes())
 
 
-def read_out(path, n, n_frames, n_frusta, T68, gpu=False, n_cams=0):
+def read_out(path, n, n_frames, n_frusta, T68, gpu=False, n_cams=0, buckets=False):
     """n_cams (YFH_CAMERA_PIPELINE runs): the frame's tuple ends in an (n_cams, 3, 16) array, the view / projection /
     view_projection matrices the Camera components hold after the frame."""
     raw = open(path, "rb").read()
@@ -66,6 +66,15 @@ def read_out(path, n, n_frames, n_frusta, T68, gpu=False, n_cams=0):
             cams = np.frombuffer(raw, np.float32, n_cams * 48, pos).reshape(n_cams, 3, 16).copy()
             pos += n_cams * 192
             res.append((w, l, a, b, vis, cams))
+            continue
+        if buckets:  # YFH_MATERIALS runs: ((material, mesh, first, count) rows, entity indices in record order)
+            (nb,) = struct.unpack_from("<I", raw, pos)
+            bk = np.frombuffer(raw, np.uint32, nb * 4, pos + 4).reshape(nb, 4).copy()
+            pos += 4 + 16 * nb
+            (nrec,) = struct.unpack_from("<Q", raw, pos)
+            rec = np.frombuffer(raw, np.uint32, nrec, pos + 8).copy()
+            pos += 8 + 4 * nrec
+            res.append((w, l, a, b, vis, (bk, rec)))
             continue
         res.append((w, l, a, b, vis))
     assert pos == len(raw)
@@ -331,6 +340,86 @@ def test_the_system_reads_cameras_and_mesh_bounds_from_the_ecs(oracle, tmp_path)
         patches = vis[-1][4]
         assert rebuilds - rebuilds_before + patches - patches_before == (1 if fi in (0, 4) else 0), f"frame {fi}: {rebuilds} rebuilds, {patches} patches"
         rebuilds_before, patches_before = rebuilds, patches
+
+
+def test_material_and_mesh_draw_buckets_from_the_ecs(oracle, tmp_path):
+    """SURVEY 8f N2, the material half (RenderApi.zig:1410-1441: the pipeline is rebound when `material.ref` changes,
+    the vertex buffer when the mesh does).  Three materials x three meshes held by Material{ref} / Mesh{ref} components;
+    the system gives every pair its own key and the device buckets frustum 0's visible entities by it.  Per frame: the
+    buckets are sorted by material, then mesh, each pair once; a bucket's records hold exactly the visible entities of
+    that pair, in draw-list order; entities without a mesh come before the first bucket; replaying the reference's
+    rebinding rule over the buckets binds every material once.  Mid-run: materials set on entities that have one (no row
+    moves), entities that change mesh, entities that lose their place in the frustum through an edit."""
+    n, levels = 30_000, 5
+    rng = np.random.default_rng(21)
+    lo = oracle.synth_level_offsets(n, levels)
+    par = oracle.synth_parents(lo)
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo[1])))
+    from yume_amd import synth
+
+    mesh_box = {0: [0, 0, 0, 0, 0, 0]}
+    for k in (1, 2, 3):
+        mesh_box[k] = [-0.5 * k, -0.25 * k - 0.5, -1.0, 0.5 * k, 0.25 * k + 0.5, 1.5]
+    mesh_of = (np.arange(n) % 4).astype(np.int64)          # 0: none
+    mat_of = ((np.arange(n) // 4) % 3).astype(np.int64)    # meaningful where mesh_of != 0
+    planes = np.stack([synth.main_camera_planes(), synth.cascade_planes()[1]]).astype(np.float32).reshape(2, 24)
+
+    def arg_u32(v):
+        m = np.zeros(16, np.float32)
+        m.view(np.uint32)[0] = v
+        return m
+
+    has_mesh = np.flatnonzero(mesh_of != 0)
+    remat = rng.choice(has_mesh, 400, replace=False)
+    remesh = rng.choice(has_mesh, 300, replace=False)
+    frames = [[],
+              [(int(e), 8, arg_u32(int(mat_of[e] + 1) % 3)) for e in remat],
+              [(int(e), 4, arg_u32(int(mesh_of[e]) % 3 + 1)) for e in remesh],
+              [(int(e), 0, oracle.compose(rng.uniform(-5, 5, 3), rng.uniform(-1, 1, 4), [1, 1, 1])) for e in np.unique(rng.integers(0, n, 300))],
+              []]
+    scene, out_c, out_g = tmp_path / "scene.bin", tmp_path / "cpu.bin", tmp_path / "gpu.bin"
+    write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], np.zeros((1, 24), np.float32), np.zeros((n, 6), np.float32), frames)
+    subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
+    env["YFH_MATERIALS"] = "1"
+    subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
+    cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
+    gpu = read_out(out_g, n, len(frames), 2, oracle.T68, gpu=True, buckets=True)
+    for fi, ((cw, cl, _, _rows, _), (gw, gl, _reb, _g_rows, vis, (bk, rec))) in enumerate(zip(cpu, gpu)):
+        for e, kind, m in frames[fi]:
+            if kind == 8:
+                mat_of[e] = int(m.view(np.uint32)[0]) % 3
+            if kind == 4:
+                mesh_of[e] = int(m.view(np.uint32)[0])
+        with np.errstate(all="ignore"):
+            assert np.array_equal(gw["m"], cw["m"], equal_nan=True) and np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi}"
+        bounds = np.array([mesh_box[int(k)] for k in mesh_of], np.float32)
+        exp_vis, _ = oracle.cull(np.ascontiguousarray(cw), bounds, planes)
+        visible = np.flatnonzero(exp_vis[0])
+        assert np.array_equal(np.sort(vis[0]), visible), f"frame {fi}: visible set"
+        assert np.array_equal(np.sort(rec), visible), f"frame {fi}: the records are the visible entities, each once"
+        # buckets: sorted by (material, mesh), every pair at most once, together all visible entities that have a mesh
+        keys = [(int(a), int(b)) for a, b, _f, _c in bk]
+        assert keys == sorted(set(keys)), f"frame {fi}: bucket order {keys}"
+        list_pos = {int(e): i for i, e in enumerate(vis[0])}  # the frustum's draw list (slot order)
+        covered = 0
+        for mat, mesh, first, count in bk:
+            ents = rec[first:first + count]
+            assert count > 0 and np.all(mesh_of[ents] == mesh + 1) and np.all(mat_of[ents] == mat), f"frame {fi}: bucket ({mat}, {mesh})"
+            want = visible[(mesh_of[visible] == mesh + 1) & (mat_of[visible] == mat)]
+            assert np.array_equal(np.sort(ents), want), f"frame {fi}: bucket ({mat}, {mesh}) misses or adds entities"
+            order = [list_pos[int(e)] for e in ents]
+            assert order == sorted(order), f"frame {fi}: bucket ({mat}, {mesh}) is not in draw-list order"
+            covered += count
+        assert covered == np.count_nonzero(mesh_of[visible] != 0)
+        first_bucket = int(min(bk[:, 2])) if len(bk) else rec.size
+        assert np.all(mesh_of[rec[:first_bucket]] == 0), f"frame {fi}: entities without a mesh come before the buckets"
+        # the reference's rebinding rule over the buckets in the order handed out: one pipeline bind per material present,
+        # one vertex-buffer bind per (material, mesh) pair
+        mats = [k[0] for k in keys]
+        assert 1 + sum(a != b for a, b in zip(mats[1:], mats[:-1])) == len(set(mats))
+        assert len(keys) == len({(int(mat_of[e]), int(mesh_of[e]) - 1) for e in visible if mesh_of[e] != 0})
+        assert len(keys) >= 6, "the scene was meant to show most of the nine pairs"
 
 
 @pytest.mark.parametrize("mode", ["incremental", "whole-columns", "no-readback"])

@@ -431,7 +431,9 @@ def test_draw_list_consumer_object_data_and_draw_records(ctx, oracle):
         assert np.array_equal(c[:, 0], per_mesh[ids[lst]])
 
 
-@pytest.mark.parametrize("n,nm,base", [(200_000, 16, 4096), (3_000_000, 16, 0), (50_000, 256, 7), (1000, 1, 0), (100_000, 3, 0)])
+@pytest.mark.parametrize("n,nm,base", [(200_000, 16, 4096), (3_000_000, 16, 0), (50_000, 256, 7), (1000, 1, 0), (100_000, 3, 0),
+                                       # more than 256 keys - one per (material, mesh) pair of a large scene: slices per wave, counters in memory
+                                       (300_000, 257, 3), (2_000_000, 4096, 0), (70_001, 1000, 5), (400_000, 65536, 11)])
 def test_mesh_buckets_are_a_stable_sort_of_the_draw_list(ctx, oracle, n, nm, base):
     """visible entities grouped by mesh id, ascending entity inside a mesh (= numpy's stable argsort
     of the list's mesh ids); records, matrices and the bucket table follow that order.  Replaying the reference's draw
@@ -474,6 +476,37 @@ def test_mesh_buckets_are_a_stable_sort_of_the_draw_list(ctx, oracle, n, nm, bas
         with pytest.raises(_lib.YumeHipError) as e:
             _lib.check(_lib.lib().yh_get_mesh_buckets(s._h, 0, None, 0, None, 0, None))
         assert e.value.code == _lib.YH_ERR_BAD_ARG
+
+
+def test_mesh_buckets_follow_a_mesh_table_that_grows_from_few_keys_to_many(ctx, oracle):
+    """The same scene bucketed with 8 keys (tiles sorted in LDS), then with 3000 (the many-keys path: its scratch is
+    allocated on the way), then with 8 again: each time numpy's stable argsort of the list's keys."""
+    from yume_amd import Scene
+
+    n, cap = 500_000, 4096
+    trs = oracle.synth_trs(n, n)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    with Scene(ctx, n, n_frusta=1, bounds_kind=2, max_meshes=cap) as s:
+        s.upload_flat()
+        s.upload_trs(trs)
+        for nm in (8, 3000, 8):
+            ids = oracle.synth_mesh_ids(n, nm, seed=77 + nm)
+            table = np.tile(np.float32([-1, -1, -1, 1, 1, 1]), (nm, 1))
+            if nm < s.n_meshes:  # a table may not shrink below the largest id in use: the ids first
+                s.upload_mesh_ids(ids)
+                s.upload_mesh_aabbs(table)
+            else:
+                s.upload_mesh_aabbs(table)
+                s.upload_mesh_ids(ids)
+            s.upload_vertex_counts(np.arange(nm, dtype=np.uint32) + 3)
+            s.frame(planes)
+            lst = s.draw_list(0)
+            order = np.argsort(ids[lst], kind="stable")
+            b, got_ids, m, c = s.mesh_buckets(0)
+            assert b.shape[0] == nm and np.array_equal(got_ids, lst[order]), nm
+            assert np.array_equal(c[:, 0], ids[lst[order]] + 3)
+            cnt = np.bincount(ids[lst], minlength=nm).astype(np.uint32)
+            assert np.array_equal(b[:, 2], cnt) and np.array_equal(b[:, 1], np.cumsum(cnt) - cnt)
 
 
 def test_mesh_buckets_need_a_mesh_table(ctx, oracle):

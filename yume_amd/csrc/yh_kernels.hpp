@@ -1263,6 +1263,164 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
     }
 }
 
+// ---- the same for MANY keys (257 .. YH_BUCKET_MAX_KEYS: one key per (material, mesh) pair of a scene) ------------------
+// With thousands of keys a 256-entry tile holds a key once or not at all, so there is nothing to sort inside a tile and
+// no room for per-key arrays in LDS.  Here every WAVE owns one contiguous slice of the list (n_slices of them: a power
+// of two chosen by the host so that keys x slices stays within 16M counters) and hist[key][slice] lives in global
+// memory only: pass 1 counts into it, k_bucket_rows_n / k_bucket_starts_n turn it into exclusive offsets, pass 2 walks
+// the slices again and, per 64 entries, lets the first lane of every distinct key fetch-and-add that key's running
+// offset of this slice (one atomic per distinct key and 64 entries, all of a wave's in flight together; the returned
+// values order the wave's visits of a key, lane ranks order the entries inside a visit: stable).  Matrices go through a
+// wave-private LDS transpose and leave as whole 64-byte rows.
+#define YH_BUCKET_MAX_KEYS 65536u
+struct BucketWideArgs {
+    BucketArgs b;
+    uint32_t n_slices;  // power of two, a multiple of 256 (4 waves per workgroup: n_slices / 4 workgroups)
+};
+
+__device__ __forceinline__ void bucket_wave_slice(const BucketWideArgs& a, uint32_t slice, uint64_t& lo, uint64_t& hi) {
+    uint64_t count = *a.b.count_ptr;
+    if (count > a.b.cap) count = a.b.cap;
+    uint64_t per = (count + a.n_slices - 1) / a.n_slices;
+    per = (per + 63u) & ~63ull;
+    lo = (uint64_t)slice * per;
+    hi = lo + per;
+    if (lo > count) lo = count;
+    if (hi > count) hi = count;
+}
+
+// rank of this lane among the wave's active lanes with the same key (lane order), their number, and whether this lane
+// is the first of them: one turn per distinct key
+__device__ __forceinline__ void match_keys(bool active, uint32_t key, uint32_t& rank, uint32_t& same_count, bool& first) {
+    rank = 0;
+    same_count = 0;
+    first = false;
+    uint64_t todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t lk = __shfl(key, leader);
+        const uint64_t same = __ballot(active && key == lk);
+        if (active && key == lk) {
+            rank = lane_rank(same);
+            same_count = (uint32_t)__popcll(same);
+            first = (int)(threadIdx.x & 63u) == leader;
+        }
+        todo &= ~same;
+    }
+}
+
+__global__ __launch_bounds__(YH_BLOCK) void k_bucketw_hist(BucketWideArgs a) {
+    const uint32_t slice = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    uint64_t lo, hi;
+    bucket_wave_slice(a, slice, lo, hi);
+    for (uint64_t i0 = lo; i0 < hi; i0 += 64u) {  // wave-uniform
+        const bool active = i0 + lane < hi;
+        const uint32_t key = active ? a.b.mesh_id[a.b.list[i0 + lane] - a.b.id_base] : 0u;
+        uint32_t rank, cnt;
+        bool first;
+        match_keys(active, key, rank, cnt, first);
+        if (first) atomicAdd(&a.b.hist[(uint64_t)key * a.n_slices + slice], cnt);  // (this wave's own counter: ordering, not contention)
+    }
+}
+
+// One workgroup per key: exclusive scan of the row's n_slices counts, total to totals[key].
+__global__ __launch_bounds__(YH_BLOCK) void k_bucket_rows_n(BucketWideArgs a) {
+    __shared__ uint32_t part[YH_BLOCK];
+    const uint32_t per = a.n_slices / YH_BLOCK;  // 1 .. 64 consecutive values per thread
+    uint32_t* row = a.b.hist + (uint64_t)blockIdx.x * a.n_slices + threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < per; ++i) sum += row[i];
+    const uint32_t inc = block_scan_256(sum, part);
+    uint32_t run = inc - sum;
+    for (uint32_t i = 0; i < per; ++i) {
+        const uint32_t v = row[i];
+        row[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == YH_BLOCK - 1) a.b.totals[blockIdx.x] = inc;
+}
+
+// One workgroup: bucket starts = exclusive scan of all keys' totals, 256 at a time with a carry; the bucket table.
+__global__ __launch_bounds__(YH_BLOCK) void k_bucket_starts_n(BucketWideArgs a) {
+    __shared__ uint32_t part[YH_BLOCK];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t m0 = 0; m0 < a.b.n_meshes; m0 += YH_BLOCK) {
+        const uint32_t m = m0 + threadIdx.x;
+        const uint32_t total = m < a.b.n_meshes ? a.b.totals[m] : 0u;
+        const uint32_t inc = block_scan_256(total, part);
+        const uint32_t before = carry;
+        if (m < a.b.n_meshes) {
+            const uint32_t first = before + inc - total;
+            a.b.starts[m] = first;
+            a.b.buckets[3 * m + 0] = m;
+            a.b.buckets[3 * m + 1] = first;
+            a.b.buckets[3 * m + 2] = total;
+        }
+        __syncthreads();
+        if (threadIdx.x == YH_BLOCK - 1) carry = before + inc;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(YH_BLOCK) void k_bucketw_scatter(BucketWideArgs a) {
+    __shared__ uint32_t rows[4][64 * 17];  // one transpose area per wave: nothing is shared between waves, no workgroup barrier
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t slice = blockIdx.x * 4u + wave;
+    uint32_t* __restrict__ mine = rows[wave];
+    uint64_t lo, hi;
+    bucket_wave_slice(a, slice, lo, hi);
+    uint32_t id_n = lo + lane < hi ? a.b.list[lo + lane] : a.b.id_base;
+    for (uint64_t i0 = lo; i0 < hi; i0 += 64u) {  // wave-uniform
+        const bool active = i0 + lane < hi;
+        const uint32_t id = id_n;
+        id_n = i0 + 64u + lane < hi ? a.b.list[i0 + 64u + lane] : a.b.id_base;  // the next entries, on their way
+        const uint32_t e = id - a.b.id_base;
+        const uint32_t key = active ? a.b.mesh_id[e] : 0u;
+        float w[16];
+        {
+            const uint64_t off = eoff<16>(e);  // (an inactive lane reads entity 0's row: in bounds)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) w[q] = lde(a.b.world, off, q);
+        }
+        uint32_t rank, cnt;
+        bool first;
+        match_keys(active, key, rank, cnt, first);
+        uint32_t base = 0;
+        if (first) base = atomicAdd(&a.b.hist[(uint64_t)key * a.n_slices + slice], cnt);  // running offset of (key, slice)
+        // every lane takes its key's base from the first lane of that key
+        uint32_t pos = 0;
+        {
+            uint64_t todo = __ballot(active);
+            while (todo) {
+                const int leader = __ffsll((unsigned long long)todo) - 1;
+                const uint32_t lk = __shfl(key, leader);
+                const uint32_t lb = __shfl(base, leader);
+                const uint64_t same = __ballot(active && key == lk);
+                if (active && key == lk) pos = a.b.starts[key] + lb + rank;
+                todo &= ~same;
+            }
+        }
+        if (active) {
+            a.b.out_list[pos] = id;
+            a.b.cmds[pos] = make_uint4(a.b.vcount ? a.b.vcount[key] : 0u, 1u, 0u, a.b.batch_offset + pos);
+        }
+        __builtin_amdgcn_wave_barrier();  // (the wave's earlier reads of `mine` stay ahead of these writes)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) mine[lane * 17 + q] = __float_as_uint(w[q]);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n_tile = (uint32_t)(hi - i0 < 64u ? hi - i0 : 64u);
+        // lanes 16 r' .. 16 r' + 15 write row r = 4 k + r' as one 64-byte piece
+#pragma unroll 4
+        for (uint32_t k = 0; k < 16u; ++k) {
+            const uint32_t r = 4u * k + (lane >> 4);
+            const uint32_t rp = (uint32_t)__shfl((int)pos, (int)r);
+            if (r < n_tile) a.b.obj[(uint64_t)rp * 16 + (lane & 15u)] = mine[r * 17 + (lane & 15u)];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Synthetic scene generator: TRS + bounds from the counter-based hash, bit-identical to
 // the oracle's host generator.  Level 0 (local index < n_level0) draws from the wide ranges.

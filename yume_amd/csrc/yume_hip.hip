@@ -119,7 +119,8 @@ struct yh_scene {
     // per-mesh buckets (yh_build_mesh_buckets): bucketed entity ids + bucket table per frustum, shared scratch
     uint32_t* blist[YH_MAX_FRUSTA] = {};
     uint32_t* bkt[YH_MAX_FRUSTA] = {};
-    uint32_t* bscratch = nullptr;     // hist [n_meshes][YH_BUCKET_SLICES] | totals | starts
+    uint32_t* bscratch = nullptr;     // hist [n_meshes][slices] | totals | starts
+    uint64_t bscratch_words = 0;
     bool bucketed[YH_MAX_FRUSTA] = {};
     void* staging = nullptr;          // device staging for AoS68 import/export
     uint64_t staging_bytes = 0;
@@ -1782,20 +1783,39 @@ extern "C" int yh_build_mesh_buckets(yh_scene* s, uint32_t frustum, uint32_t bat
     if (s->desc.bounds_kind != YH_BOUNDS_MESH_TABLE)
         return fail(ctx, YH_ERR_STATE, "yh_build_mesh_buckets: the scene has no mesh table (entities carry no mesh id)");
     if (frustum >= s->last_n_frusta) return fail(ctx, YH_ERR_STATE, "yh_build_mesh_buckets: frustum %u was not culled by the last frame", frustum);
-    if (s->n_meshes < 1 || s->n_meshes > YH_BUCKET_MAX_MESHES)
-        return fail(ctx, YH_ERR_UNSUPPORTED, "yh_build_mesh_buckets: %u meshes, 1..%u supported", s->n_meshes, YH_BUCKET_MAX_MESHES);
+    if (s->n_meshes < 1 || s->n_meshes > YH_BUCKET_MAX_KEYS)
+        return fail(ctx, YH_ERR_UNSUPPORTED, "yh_build_mesh_buckets: %u meshes, 1..%u supported", s->n_meshes, YH_BUCKET_MAX_KEYS);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc = flush_expand(s)) return rc;
     if (!s->obj[frustum]) {
         HIP_TRY(ctx, hipMalloc((void**)&s->obj[frustum], s->draw_cap * 64));
         HIP_TRY(ctx, hipMalloc((void**)&s->cmd[frustum], s->draw_cap * 16));
     }
-    const uint32_t M = std::min<uint32_t>(s->desc.max_meshes, YH_BUCKET_MAX_MESHES);
+    // Up to 256 keys: 4096 workgroup slices, tiles sorted inside LDS.  More (one key per (material, mesh) pair of a large
+    // scene): one slice per WAVE, counters in global memory only, keys x slices kept within 16M counters.
+    const uint32_t M = std::min<uint32_t>(std::max<uint32_t>(s->desc.max_meshes, 1u), YH_BUCKET_MAX_KEYS);
+    const bool wide = s->n_meshes > YH_BUCKET_MAX_MESHES || getenv("YH_BUCKET_WIDE") != nullptr;  // (the knob: A/B runs of the two paths)
+    uint32_t slices = YH_BUCKET_SLICES;
+    if (wide) {
+        slices = 16384u;
+        while (slices > 256u && (uint64_t)slices * s->n_meshes > (16ull << 20)) slices >>= 1;
+    }
     if (!s->blist[frustum]) {
         HIP_TRY(ctx, hipMalloc((void**)&s->blist[frustum], s->draw_cap * 4));
         HIP_TRY(ctx, hipMalloc((void**)&s->bkt[frustum], (uint64_t)M * 12));
     }
-    if (!s->bscratch) HIP_TRY(ctx, hipMalloc((void**)&s->bscratch, ((uint64_t)M * YH_BUCKET_SLICES + 2 * M) * 4));
+    const uint64_t scratch_words = (uint64_t)s->n_meshes * slices + 2ull * M;
+    if (scratch_words > s->bscratch_words) {  // (the mesh table grew, or went from few keys to many)
+        if (s->bscratch) {
+            if (int rc = sync_scene(s)) return rc;
+            HIP_TRY(ctx, hipFree(s->bscratch));
+            s->bscratch = nullptr;
+            s->bscratch_words = 0;
+        }
+        const uint64_t words = scratch_words + scratch_words / 4;
+        HIP_TRY(ctx, hipMalloc((void**)&s->bscratch, words * 4));
+        s->bscratch_words = words;
+    }
     BucketArgs a{};
     a.list = s->draw[frustum];
     a.count_ptr = s->counts + frustum;
@@ -1804,7 +1824,7 @@ extern "C" int yh_build_mesh_buckets(yh_scene* s, uint32_t frustum, uint32_t bat
     a.mesh_id = s->mesh_id;
     a.n_meshes = s->n_meshes;
     a.hist = s->bscratch;
-    a.totals = s->bscratch + (uint64_t)M * YH_BUCKET_SLICES;
+    a.totals = s->bscratch + (uint64_t)s->n_meshes * slices;
     a.starts = a.totals + M;
     a.buckets = s->bkt[frustum];
     a.world = s->world;
@@ -1813,6 +1833,20 @@ extern "C" int yh_build_mesh_buckets(yh_scene* s, uint32_t frustum, uint32_t bat
     a.out_list = s->blist[frustum];
     a.obj = s->obj[frustum];
     a.cmds = s->cmd[frustum];
+    if (wide) {
+        BucketWideArgs w{};
+        w.b = a;
+        w.n_slices = slices;
+        HIP_TRY(ctx, hipMemsetAsync(a.hist, 0, (uint64_t)s->n_meshes * slices * 4, ctx->stream));
+        hipLaunchKernelGGL(k_bucketw_hist, dim3(slices / 4), dim3(YH_BLOCK), 0, ctx->stream, w);
+        hipLaunchKernelGGL(k_bucket_rows_n, dim3(s->n_meshes), dim3(YH_BLOCK), 0, ctx->stream, w);
+        hipLaunchKernelGGL(k_bucket_starts_n, dim3(1), dim3(YH_BLOCK), 0, ctx->stream, w);
+        hipLaunchKernelGGL(k_bucketw_scatter, dim3(slices / 4), dim3(YH_BLOCK), 0, ctx->stream, w);
+        HIP_TRY(ctx, hipGetLastError());
+        s->frame_pending = true;
+        s->bucketed[frustum] = true;
+        return YH_OK;
+    }
     const dim3 grid(YH_BUCKET_SLICES);
     hipLaunchKernelGGL(k_bucket_hist, grid, dim3(YH_BLOCK), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_bucket_rows, dim3(s->n_meshes), dim3(YH_BLOCK), 0, ctx->stream, a);

@@ -124,7 +124,10 @@ struct GpuTransformCullSystem {
     uint32_t n_meshes;                        /* entries of the mesh table of the last upload (entry 0: the empty box) */
     float* mesh_table;                        /* host copy of the table: MESH_TABLE_MAX x {mins, maxs} */
     uint32_t* mesh_vcount;
-    Map mesh_index;                           /* mesh pointer -> table entry */
+    Map mesh_index;                           /* (material, mesh) pointer pair -> table entry (pair_key) */
+    ecs_entity_t material_id;                 /* Material{ ref: *shading.Material } (components/material.zig), 0: meshes only */
+    const void** entry_material;              /* per table entry: the pair it stands for (NULL, NULL for entry 0 and overrides) */
+    const void** entry_mesh;
     uint32_t mesh_count;                      /* entries of the host copy (patch() appends; n_meshes follows at the next upload) */
 
     /* incremental mode: only rows whose onSet fired go up, only rows the frame touched come back */
@@ -151,7 +154,7 @@ struct GpuTransformCullSystem {
     uint32_t epoch;
     uint32_t* slot_buf;      /* n entries: slots of a sparse upload / of the changed rows */
     int slot_buf_pinned;
-    ecs_entity_t observers[7];
+    ecs_entity_t observers[8];
     uint64_t last_up_rows, last_down_rows;
     double last_ms[6];       /* the last frame's wall time: tables + inputs, rows up, device frame, rows down and placed; of the first: query walk, slot-order rebuild */
 
@@ -613,11 +616,14 @@ done:
 static int mesh_table_reset(GpuTransformCullSystem* s) {
     if (!s->mesh_table) s->mesh_table = (float*)malloc(sizeof(float) * 6 * (size_t)MESH_TABLE_MAX);
     if (!s->mesh_vcount) s->mesh_vcount = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)MESH_TABLE_MAX);
+    if (!s->entry_material) s->entry_material = (const void**)malloc(sizeof(void*) * (size_t)MESH_TABLE_MAX);
+    if (!s->entry_mesh) s->entry_mesh = (const void**)malloc(sizeof(void*) * (size_t)MESH_TABLE_MAX);
     free(s->mesh_index.e);
     s->mesh_index.e = NULL;
-    if (!s->mesh_table || !s->mesh_vcount || map_init(&s->mesh_index, 4096) != 0) return YH_ERR_OOM;
+    if (!s->mesh_table || !s->mesh_vcount || !s->entry_material || !s->entry_mesh || map_init(&s->mesh_index, 4096) != 0) return YH_ERR_OOM;
     memset(s->mesh_table, 0, sizeof(float) * 6); /* entry 0: no mesh = an empty box at the origin */
     s->mesh_vcount[0] = 0;
+    s->entry_material[0] = s->entry_mesh[0] = NULL;
     s->mesh_count = 1;
     return YH_OK;
 }
@@ -626,11 +632,27 @@ static int mesh_table_append(GpuTransformCullSystem* s, const float mm[6], uint3
     *id = s->mesh_count++;
     memcpy(s->mesh_table + 6 * (size_t)*id, mm, 24);
     s->mesh_vcount[*id] = vertices;
+    s->entry_material[*id] = s->entry_mesh[*id] = NULL;
     return YH_OK;
 }
-/* table entry of the mesh a Mesh{ref} points to: looked up, or appended from the mesh's BoundingBox{mins, maxs} */
-static int mesh_table_entry(GpuTransformCullSystem* s, const uint8_t* mesh, uint32_t* id) {
-    if (map_get(&s->mesh_index, (ecs_entity_t)(uintptr_t)mesh, id)) return YH_OK;
+/* The draw loop rebinds the pipeline when the material changes and the vertex buffer when the mesh does
+ * (RenderApi.zig:1411, 1434): a table entry - the key the device buckets a draw list by - stands for one (material,
+ * mesh) pair.  The map is keyed by a 64-bit mix of the two pointers; a hit is checked against the entry's own pair and
+ * a (never yet seen) collision of two pairs moves on to the next key of the chain. */
+static uint64_t pair_key(const void* material, const void* mesh, uint32_t attempt) {
+    uint64_t k = (uint64_t)(uintptr_t)mesh ^ (hash64((uint64_t)(uintptr_t)material + 0x9E3779B97F4A7C15ull * (attempt + 1u)) << 1);
+    if (!material && !attempt) k = (uint64_t)(uintptr_t)mesh; /* meshes only: the pointer itself, as before */
+    return k ? k : 1;
+}
+/* table entry of a (material, mesh) pair: looked up, or appended from the mesh's BoundingBox{mins, maxs} */
+static int mesh_table_entry(GpuTransformCullSystem* s, const uint8_t* mesh, const void* material, uint32_t* id) {
+    uint64_t key = 0;
+    for (uint32_t attempt = 0;; ++attempt) {
+        key = pair_key(material, mesh, attempt);
+        if (!map_get(&s->mesh_index, (ecs_entity_t)key, id)) break;
+        if (s->entry_mesh[*id] == (const void*)mesh && s->entry_material[*id] == material) return YH_OK;
+        if (attempt == 64) return YH_ERR_STATE;
+    }
     if (s->mesh_index.cap < (uint64_t)s->mesh_count * 2 + 2) {
         Map bigger = {0};
         if (map_init(&bigger, s->mesh_index.cap) != 0) return YH_ERR_OOM; /* (map_init doubles what it is asked for) */
@@ -648,7 +670,11 @@ static int mesh_table_entry(GpuTransformCullSystem* s, const uint8_t* mesh, uint
         vertices = vc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)vc;
     }
     const int rc = mesh_table_append(s, mm, vertices, id);
-    if (rc == YH_OK) map_put(&s->mesh_index, (ecs_entity_t)(uintptr_t)mesh, *id);
+    if (rc == YH_OK) {
+        s->entry_material[*id] = material;
+        s->entry_mesh[*id] = mesh;
+        map_put(&s->mesh_index, (ecs_entity_t)key, *id);
+    }
     return rc;
 }
 /* mesh ids of one batch's rows into ids[0 .. count): the Mesh column where the table has one, 0 elsewhere, an entry of
@@ -658,15 +684,20 @@ static int mesh_ids_of_batch(GpuTransformCullSystem* s, const Batch* b, uint32_t
     const int32_t col = b->table ? ecs_table_get_column_index(s->world, b->table, s->mesh_id) : -1;
     if (col >= 0) {
         const uint8_t* const* refs = (const uint8_t* const*)ecs_table_get_column(b->table, col, 0);
+        const int32_t mcol = s->material_id ? ecs_table_get_column_index(s->world, b->table, s->material_id) : -1;
+        const void* const* mats = mcol >= 0 ? (const void* const*)ecs_table_get_column(b->table, mcol, 0) : NULL;
         const uint8_t* prev = NULL;
+        const void* prev_mat = NULL;
         uint32_t prev_id = 0;
-        for (uint32_t r = 0; r < b->count; ++r) { /* one hash lookup per run of rows that share a mesh */
+        for (uint32_t r = 0; r < b->count; ++r) { /* one hash lookup per run of rows that share a mesh and a material */
             const uint8_t* mesh = refs[r];
+            const void* mat = mats ? mats[r] : NULL;
             if (!mesh) continue;
-            if (mesh != prev) {
-                const int rc = mesh_table_entry(s, mesh, &prev_id);
+            if (mesh != prev || mat != prev_mat) {
+                const int rc = mesh_table_entry(s, mesh, mat, &prev_id);
                 if (rc != YH_OK) return rc;
                 prev = mesh;
+                prev_mat = mat;
             }
             ids[r] = prev_id;
         }
@@ -2248,6 +2279,75 @@ int GpuTransformCullSystem_setMeshComponent(GpuTransformCullSystem* s, ecs_entit
     return YH_OK;
 }
 
+int GpuTransformCullSystem_setMaterialComponent(GpuTransformCullSystem* s, ecs_entity_t material) {
+    if (!s || !material) return YH_ERR_BAD_ARG;
+    if (!s->mesh_id) return YH_ERR_STATE; /* setMeshComponent first: a key is a (material, mesh) pair */
+    const ecs_type_info_t* ti = ecs_get_type_info(s->world, material);
+    if (!ti || ti->size != (ecs_size_t)sizeof(void*)) return YH_ERR_BAD_ARG; /* Material{ ref: *shading.Material } */
+    s->material_id = material;
+    if (!s->observers[7]) { /* a Material set on an entity that already has one moves no row: only the keys go stale */
+        ecs_observer_desc_t od;
+        memset(&od, 0, sizeof od);
+        od.query.terms[0].id = material;
+        od.events[0] = EcsOnSet;
+        od.callback = note_mesh_set;
+        od.ctx = s;
+        s->observers[7] = ecs_observer_init(s->world, &od);
+    }
+    s->bounds_stale = 1;
+    return YH_OK;
+}
+
+static int by_pair(const void* a, const void* b) {
+    const GpuDrawBucket* x = (const GpuDrawBucket*)a;
+    const GpuDrawBucket* y = (const GpuDrawBucket*)b;
+    if (x->material != y->material) return (uintptr_t)x->material < (uintptr_t)y->material ? -1 : 1;
+    if (x->mesh != y->mesh) return (uintptr_t)x->mesh < (uintptr_t)y->mesh ? -1 : 1;
+    return 0;
+}
+
+int GpuTransformCullSystem_drawBuckets(GpuTransformCullSystem* s, uint32_t frustum, uint32_t batch_offset, GpuDrawBucket* buckets,
+                                       uint32_t cap_buckets, uint32_t* n_buckets, ecs_entity_t* entities, uint64_t cap,
+                                       uint64_t* written) {
+    if (!s || !n_buckets || !written) return YH_ERR_BAD_ARG;
+    *n_buckets = 0;
+    *written = 0;
+    if (!s->scene || s->scene_bounds_kind != YH_BOUNDS_MESH_TABLE || frustum >= s->n_frusta) return YH_ERR_STATE;
+    int rc = yh_build_mesh_buckets(s->scene, frustum, batch_offset);
+    if (rc != YH_OK) return rc;
+    const uint32_t nm = s->n_meshes;
+    yh_bucket* raw = (yh_bucket*)malloc(sizeof(yh_bucket) * (nm ? nm : 1));
+    uint32_t* slots = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(s->n_slots ? s->n_slots : 1));
+    if (!raw || !slots) rc = YH_ERR_OOM;
+    uint64_t total = 0;
+    if (rc == YH_OK) rc = yh_get_mesh_buckets(s->scene, frustum, raw, nm, slots, s->n_slots, &total);
+    if (rc == YH_OK) {
+        uint32_t k = 0;
+        for (uint32_t m = 0; m < nm; ++m) { /* entries with something to draw: a mesh, and visible entities */
+            if (!raw[m].count || !s->entry_mesh[m]) continue;
+            if (buckets && k < cap_buckets) {
+                buckets[k].material = s->entry_material[m];
+                buckets[k].mesh = s->entry_mesh[m];
+                buckets[k].first = raw[m].first;
+                buckets[k].count = raw[m].count;
+            }
+            ++k;
+        }
+        *n_buckets = k;
+        *written = total;
+        if (buckets && k > cap_buckets) rc = YH_ERR_CAPACITY;
+        else if (buckets) qsort(buckets, k, sizeof(GpuDrawBucket), by_pair); /* material first: one pipeline bind per material */
+        if (entities) {
+            if (total > cap) rc = rc == YH_OK ? YH_ERR_CAPACITY : rc;
+            else
+                for (uint64_t i = 0; i < total; ++i) entities[i] = s->entity_of_slot[slots[i]];
+        }
+    }
+    free(raw);
+    free(slots);
+    return rc;
+}
+
 int GpuTransformCullSystem_invalidateBounds(GpuTransformCullSystem* s) {
     if (!s) return YH_ERR_BAD_ARG;
     s->bounds_stale = 1;
@@ -2333,6 +2433,8 @@ void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     for (uint32_t l = 0; l < YH_MAX_LEVELS; ++l) free(s->free_runs[l]);
     free(s->mesh_table);
     free(s->mesh_vcount);
+    free((void*)s->entry_material);
+    free((void*)s->entry_mesh);
     free(s->mesh_index.e);
     free(s->cached_slot);
     free(s);

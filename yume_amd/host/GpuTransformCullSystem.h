@@ -80,6 +80,28 @@ int GpuTransformCullSystem_setCameraPipeline(GpuTransformCullSystem* s, const Gp
 int GpuTransformCullSystem_setCameraAspect(GpuTransformCullSystem* s, float aspect);
 int GpuTransformCullSystem_setMeshComponent(GpuTransformCullSystem* s, ecs_entity_t mesh, uint32_t bounds_offset,
                                             int32_t vertices_count_offset);
+/* Material x mesh draw buckets (engine/GAL/vulkan/RenderApi.zig:1410-1441: the draw loop binds the
+ * pipeline and its descriptor sets whenever `material.ref` differs from the previous object's, the vertex buffer
+ * whenever the mesh does).  setMaterialComponent: the id of the Material component (`Material{ ref: *shading.Material }`,
+ * engine/components/material.zig; after setMeshComponent).  Every distinct (material, mesh) pair among the entities
+ * then gets its own entry of the device scene's mesh table - same AABB and vertex count for entries that share a mesh -
+ * so yh_build_mesh_buckets groups a frustum's visible entities by pair; Material sets and structural changes are
+ * followed like Mesh sets.  Up to 65535 pairs (+ setBounds overrides).
+ * drawBuckets: builds the buckets of `frustum` on the device (object data and draw records in bucket order, record i =
+ * {vertices_count, 1, 0, batch_offset + i}: yh_object_data_device) and returns the non-empty ones that have a mesh,
+ * SORTED BY MATERIAL, THEN MESH (pointer order): walking them in that order binds every pipeline once and every vertex
+ * buffer once per material; records [first, first + count) of a bucket are one vkCmdDrawIndirect.  entities (optional):
+ * the entity behind every record, record order (all `written` of them: entities without a mesh are listed too, in the
+ * records before the first bucket's).  YH_ERR_CAPACITY with *n_buckets / *written = what is needed.               */
+typedef struct GpuDrawBucket {
+    const void* material; /* shading.Material*, NULL for entities without a Material */
+    const void* mesh;     /* meshes.Mesh* */
+    uint32_t first, count;
+} GpuDrawBucket;
+int GpuTransformCullSystem_setMaterialComponent(GpuTransformCullSystem* s, ecs_entity_t material);
+int GpuTransformCullSystem_drawBuckets(GpuTransformCullSystem* s, uint32_t frustum, uint32_t batch_offset, GpuDrawBucket* buckets,
+                                       uint32_t cap_buckets, uint32_t* n_buckets, ecs_entity_t* entities, uint64_t cap,
+                                       uint64_t* written);
 int GpuTransformCullSystem_invalidateBounds(GpuTransformCullSystem* s);
 ecs_entity_t GpuTransformCullSystem_frustumCamera(const GpuTransformCullSystem* s, uint32_t frustum);
 uint32_t GpuTransformCullSystem_frusta(const GpuTransformCullSystem* s);

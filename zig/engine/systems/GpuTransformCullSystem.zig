@@ -17,6 +17,7 @@ const LocalTransform = ecs.components.LocalTransform;
 const WorldTransform = ecs.components.WorldTransform;
 const Camera = ecs.components.Camera;
 const Mesh = ecs.components.Mesh;
+const Material = ecs.components.Material;
 
 pub const State = opaque {};
 
@@ -32,6 +33,9 @@ pub const CameraLayout = extern struct { kind_offset: u32, options_offset: u32, 
 extern fn GpuTransformCullSystem_setCameraPipeline(s: *State, layout: ?*const CameraLayout, aspect: f32) c_int;
 extern fn GpuTransformCullSystem_setCameraAspect(s: *State, aspect: f32) c_int;
 extern fn GpuTransformCullSystem_setMeshComponent(s: *State, mesh: c.ecs_entity_t, bounds_offset: u32, vertices_count_offset: i32) c_int;
+pub const DrawBucket = extern struct { material: ?*const anyopaque, mesh: ?*const anyopaque, first: u32, count: u32 };
+extern fn GpuTransformCullSystem_setMaterialComponent(s: *State, material: c.ecs_entity_t) c_int;
+extern fn GpuTransformCullSystem_drawBuckets(s: *State, frustum: u32, batch_offset: u32, buckets: ?[*]DrawBucket, cap_buckets: u32, n_buckets: *u32, entities: ?[*]c.ecs_entity_t, cap: u64, written: *u64) c_int;
 extern fn GpuTransformCullSystem_invalidateBounds(s: *State) c_int;
 extern fn GpuTransformCullSystem_frustumCamera(s: *const State, frustum: u32) c.ecs_entity_t;
 extern fn GpuTransformCullSystem_frusta(s: *const State) u32;
@@ -102,6 +106,8 @@ pub fn registerTo(world: ecs.World) ecs.Entity {
             @offsetOf(meshes.Mesh, "bounds"),
             @offsetOf(meshes.Mesh, "vertices_count"),
         );
+    // ... and one draw bucket per (material, mesh) pair (the draw loop's rebinding rule, RenderApi.zig:1411, 1434)
+    if (last_status == 0) last_status = GpuTransformCullSystem_setMaterialComponent(state.?, ecs.typeId(Material));
     return sys;
 }
 
@@ -159,6 +165,17 @@ pub fn frustumCamera(f: u32) ecs.Entity {
 /// (RenderApi.zig:1380-1434) iterates this list instead of every MeshRenderer.
 pub fn visible(frustum: u32, out: []ecs.Entity) []ecs.Entity {
     const n = GpuTransformCullSystem_visible(state.?, frustum, out.ptr, out.len);
+    return out[0..@min(n, out.len)];
+}
+
+/// Frustum `frustum`'s visible entities as draw buckets, one per (material, mesh) pair, sorted by material and then
+/// mesh: the draw loop (RenderApi.zig:1410-1441) binds `material.ref.pipeline` once per run of equal materials, the
+/// vertex buffer once per bucket, and issues one vkCmdDrawIndirect over records [first, first + count) of the
+/// device-side draw records (hip.yh_object_data_device) - instead of one vkCmdDraw per object.
+pub fn drawBuckets(frustum: u32, batch_offset: u32, out: []DrawBucket) []DrawBucket {
+    var n: u32 = 0;
+    var records: u64 = 0;
+    last_status = GpuTransformCullSystem_drawBuckets(state.?, frustum, batch_offset, out.ptr, @intCast(out.len), &n, null, 0, &records);
     return out[0..@min(n, out.len)];
 }
 
