@@ -489,10 +489,12 @@ def test_mesh_buckets_follow_a_mesh_table_that_grows_from_few_keys_to_many(ctx, 
     with Scene(ctx, n, n_frusta=1, bounds_kind=2, max_meshes=cap) as s:
         s.upload_flat()
         s.upload_trs(trs)
+        before = 0
         for nm in (8, 3000, 8):
             ids = oracle.synth_mesh_ids(n, nm, seed=77 + nm)
             table = np.tile(np.float32([-1, -1, -1, 1, 1, 1]), (nm, 1))
-            if nm < s.n_meshes:  # a table may not shrink below the largest id in use: the ids first
+            before, shrinking = nm, nm < before
+            if shrinking:  # a table may not shrink below the largest id in use: the ids first
                 s.upload_mesh_ids(ids)
                 s.upload_mesh_aabbs(table)
             else:

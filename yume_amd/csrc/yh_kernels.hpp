@@ -114,6 +114,13 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a workgroup-scope fence over every address space:
+// the compiler puts s_waitcnt vmcnt(0) in front of it, i.e. every global load a thread has in flight must have landed
+// and every global store must have been ACKNOWLEDGED before the barrier - which serialises a software pipeline whose
+// stages talk to each other through LDS alone (k_bucket_scatter: next tile's rows in flight, last tile's rows on their
+// way out).  Only for kernels whose threads exchange data through LDS and nothing else between two barriers.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- stage 3 back end, part 1: wavefront ballots ---------------------------------------------------------
 // Every wave owns exactly one 64-entity chunk (launches are chunk-aligned), so its ballot IS the chunk's
 // visibility word.  Lane 0 stores it: no LDS, no barrier, no atomic on a shared address (tile counters fed by
@@ -1069,12 +1076,11 @@ __global__ __launch_bounds__(YH_BLOCK) void k_build_objects(const float* __restr
 // ---------------------------------------------------------------------------------------------------
 // Per-mesh bucketing of a draw list.  The reference's draw loop rebinds the vertex buffer
 // whenever "mesh != previous mesh" (RenderApi.zig:1434): handing it the visible entities grouped by mesh makes that
-// one bind per mesh.  A stable counting sort by mesh id: YH_BUCKET_SLICES workgroups own one contiguous slice of the
+// one bind per mesh.  A stable counting sort by mesh id: n_slices workgroups own one contiguous slice of the
 // (ascending) list each; pass 1 histograms the slices, two small launches turn hist[mesh][slice] into output offsets,
 // pass 2 walks every slice again, 256 entries at a time: the tile is sorted by mesh inside LDS (ballot ranks per
 // wave, wave and mesh offsets by a scan) together with its model matrices, and leaves in bucket order, so entity id,
 // matrix and draw record go out in runs of consecutive positions — inside a bucket the entities stay ascending.
-#define YH_BUCKET_SLICES 4096u
 #define YH_BUCKET_MAX_MESHES 256u
 
 struct BucketArgs {
@@ -1084,7 +1090,8 @@ struct BucketArgs {
     uint32_t id_base;
     const uint32_t* mesh_id;
     uint32_t n_meshes;
-    uint32_t* hist;    // [n_meshes][YH_BUCKET_SLICES] counts, then (k_bucket_rows) exclusive offsets inside the row
+    uint32_t n_slices; // slices the list is cut into (a multiple of 256, chosen by the host)
+    uint32_t* hist;    // [n_meshes][n_slices] counts, then (k_bucket_rows) exclusive offsets inside the row
     uint32_t* totals;  // [n_meshes]
     uint32_t* starts;  // [n_meshes] first output position of each bucket
     uint32_t* buckets; // [n_meshes] x {mesh, first, count}
@@ -1099,7 +1106,7 @@ struct BucketArgs {
 __device__ __forceinline__ void bucket_slice(const BucketArgs& a, uint32_t slice, uint64_t& lo, uint64_t& hi) {
     uint64_t count = *a.count_ptr;
     if (count > a.cap) count = a.cap;
-    uint64_t per = (count + YH_BUCKET_SLICES - 1) / YH_BUCKET_SLICES;
+    uint64_t per = (count + a.n_slices - 1) / a.n_slices;
     per = (per + (YH_BLOCK - 1)) & ~(uint64_t)(YH_BLOCK - 1);
     lo = (uint64_t)slice * per;
     hi = lo + per;
@@ -1115,7 +1122,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_hist(BucketArgs a) {
     bucket_slice(a, blockIdx.x, lo, hi);
     for (uint64_t i = lo + threadIdx.x; i < hi; i += YH_BLOCK) atomicAdd(&h[a.mesh_id[a.list[i] - a.id_base]], 1u);
     __syncthreads();
-    for (uint32_t m = threadIdx.x; m < a.n_meshes; m += YH_BLOCK) a.hist[(uint64_t)m * YH_BUCKET_SLICES + blockIdx.x] = h[m];
+    for (uint32_t m = threadIdx.x; m < a.n_meshes; m += YH_BLOCK) a.hist[(uint64_t)m * a.n_slices + blockIdx.x] = h[m];
 }
 
 // Inclusive scan of one value per thread over the workgroup (256 threads): inside each wave by lane shuffles, the four
@@ -1136,39 +1143,63 @@ __device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t* part) {
     return before + inc;
 }
 
-// One workgroup per mesh: exclusive scan of the row's YH_BUCKET_SLICES counts (16 per thread), total to totals[m].
-__global__ __launch_bounds__(YH_BLOCK) void k_bucket_rows(BucketArgs a) {
-    constexpr uint32_t PER = YH_BUCKET_SLICES / YH_BLOCK;
-    __shared__ uint32_t part[YH_BLOCK];
-    uint32_t* row = a.hist + (uint64_t)blockIdx.x * YH_BUCKET_SLICES + threadIdx.x * PER;
-    uint32_t v[PER], sum = 0;
+// (the same between LDS-only barriers: k_bucket_scatter)
+__device__ __forceinline__ uint32_t block_scan_256_lds(uint32_t v, uint32_t* part) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
 #pragma unroll
-    for (uint32_t i = 0; i < PER; ++i) {
-        v[i] = row[i];
-        sum += v[i];
+    for (uint32_t o = 1; o < 64u; o <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)inc, o);
+        if (lane >= o) inc += u;
     }
+    if (lane == 63u) part[wave] = inc;
+    lds_barrier();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += part[w];
+    lds_barrier();
+    return before + inc;
+}
+
+// One workgroup per key: exclusive scan of the row's n_slices counts (n_slices / 256 consecutive values per thread),
+// total to totals[key].
+__global__ __launch_bounds__(YH_BLOCK) void k_bucket_rows(BucketArgs a) {
+    __shared__ uint32_t part[YH_BLOCK];
+    const uint32_t per = a.n_slices / YH_BLOCK;
+    uint32_t* row = a.hist + (uint64_t)blockIdx.x * a.n_slices + threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < per; ++i) sum += row[i];
     const uint32_t inc = block_scan_256(sum, part);
     uint32_t run = inc - sum;
-#pragma unroll
-    for (uint32_t i = 0; i < PER; ++i) {
+    for (uint32_t i = 0; i < per; ++i) {
+        const uint32_t v = row[i];
         row[i] = run;
-        run += v[i];
+        run += v;
     }
     if (threadIdx.x == YH_BLOCK - 1) a.totals[blockIdx.x] = inc;
 }
 
-// One workgroup: bucket starts = exclusive scan of the totals; the bucket table the renderer reads.
+// One workgroup: bucket starts = exclusive scan of all keys' totals, 256 at a time with a carry; the bucket table the
+// renderer reads.
 __global__ __launch_bounds__(YH_BLOCK) void k_bucket_starts(BucketArgs a) {
     __shared__ uint32_t part[YH_BLOCK];
-    const uint32_t m = threadIdx.x;
-    const uint32_t total = m < a.n_meshes ? a.totals[m] : 0u;
-    const uint32_t inc = block_scan_256(total, part);
-    if (m < a.n_meshes) {
-        const uint32_t first = inc - total;
-        a.starts[m] = first;
-        a.buckets[3 * m + 0] = m;
-        a.buckets[3 * m + 1] = first;
-        a.buckets[3 * m + 2] = total;
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t m0 = 0; m0 < a.n_meshes; m0 += YH_BLOCK) {
+        const uint32_t m = m0 + threadIdx.x;
+        const uint32_t total = m < a.n_meshes ? a.totals[m] : 0u;
+        const uint32_t inc = block_scan_256(total, part);
+        const uint32_t before = carry;
+        if (m < a.n_meshes) {
+            const uint32_t first = before + inc - total;
+            a.starts[m] = first;
+            a.buckets[3 * m + 0] = m;
+            a.buckets[3 * m + 1] = first;
+            a.buckets[3 * m + 2] = total;
+        }
+        __syncthreads();
+        if (threadIdx.x == YH_BLOCK - 1) carry = before + inc;
+        __syncthreads();
     }
 }
 
@@ -1180,7 +1211,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
     __shared__ uint32_t s_pos[YH_BLOCK], s_id[YH_BLOCK], s_vc[YH_BLOCK];  // the tile in bucket order
     __shared__ uint32_t rows[YH_BLOCK * 17];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    for (uint32_t m = tid; m < a.n_meshes; m += YH_BLOCK) base[m] = a.starts[m] + a.hist[(uint64_t)m * YH_BUCKET_SLICES + blockIdx.x];
+    for (uint32_t m = tid; m < a.n_meshes; m += YH_BLOCK) base[m] = a.starts[m] + a.hist[(uint64_t)m * a.n_slices + blockIdx.x];
     uint64_t lo, hi;
     bucket_slice(a, blockIdx.x, lo, hi);
     // Two-stage software pipeline over the slice's tiles: while tile k is sorted and written, the rows and mesh ids of
@@ -1208,7 +1239,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
         }
         const uint32_t id_nn = i0 + 2 * YH_BLOCK + tid < hi ? a.list[i0 + 2 * YH_BLOCK + tid] : a.id_base;
         for (uint32_t m = tid; m < a.n_meshes; m += YH_BLOCK) wcnt[0][m] = wcnt[1][m] = wcnt[2][m] = wcnt[3][m] = 0;
-        __syncthreads();
+        lds_barrier();
         const bool active = tid < n_tile;
         const uint32_t id = id_c;
         const uint32_t m = active ? m_c : 0xFFFFFFFFu;
@@ -1223,7 +1254,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
             if ((int)lane == leader) wcnt[wave][lm] = (uint32_t)__popcll(same);
             todo &= ~same;
         }
-        __syncthreads();
+        lds_barrier();
         // per mesh: counts of the four waves -> exclusive wave offsets, tile total -> tile-local start by a scan
         uint32_t tile_cnt = 0;
         if (tid < a.n_meshes) {
@@ -1234,9 +1265,9 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
                 tile_cnt += c;
             }
         }
-        const uint32_t inc = block_scan_256(tile_cnt, part);  // (ends with a barrier)
+        const uint32_t inc = block_scan_256_lds(tile_cnt, part);  // (ends with a barrier)
         if (tid < a.n_meshes) lstart[tid] = inc - tile_cnt;
-        __syncthreads();
+        lds_barrier();
         if (active) {
             const uint32_t in_bucket = wcnt[wave][m] + rank;
             const uint32_t ls = lstart[m] + in_bucket;
@@ -1246,15 +1277,17 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) rows[ls * 17 + q] = __float_as_uint(w_c[q]);
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < a.n_meshes) base[tid] += tile_cnt;
         if (tid < n_tile) {
             const uint32_t pos = s_pos[tid];
             a.out_list[pos] = s_id[tid];
             a.cmds[pos] = make_uint4(s_vc[tid], 1u, 0u, a.batch_offset + pos);
         }
-        for (uint32_t i = tid; i < n_tile * 16u; i += YH_BLOCK) a.obj[(uint64_t)s_pos[i >> 4] * 16 + (i & 15u)] = rows[(i >> 4) * 17 + (i & 15u)];
-        __syncthreads();
+        // (streaming stores: the rows are written once and read by another engine; 2.12 -> 1.94 ms at 64M / 16 meshes)
+        for (uint32_t i = tid; i < n_tile * 16u; i += YH_BLOCK)
+            __builtin_nontemporal_store(rows[(i >> 4) * 17 + (i & 15u)], &a.obj[(uint64_t)s_pos[i >> 4] * 16 + (i & 15u)]);
+        lds_barrier();
         id_c = id_n;
         id_n = id_nn;
         m_c = m_n;
@@ -1267,20 +1300,15 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
 // With thousands of keys a 256-entry tile holds a key once or not at all, so there is nothing to sort inside a tile and
 // no room for per-key arrays in LDS.  Here every WAVE owns one contiguous slice of the list (n_slices of them: a power
 // of two chosen by the host so that keys x slices stays within 16M counters) and hist[key][slice] lives in global
-// memory only: pass 1 counts into it, k_bucket_rows_n / k_bucket_starts_n turn it into exclusive offsets, pass 2 walks
+// memory only: pass 1 counts into it, k_bucket_rows / k_bucket_starts turn it into exclusive offsets, pass 2 walks
 // the slices again and, per 64 entries, lets the first lane of every distinct key fetch-and-add that key's running
 // offset of this slice (one atomic per distinct key and 64 entries, all of a wave's in flight together; the returned
 // values order the wave's visits of a key, lane ranks order the entries inside a visit: stable).  Matrices go through a
 // wave-private LDS transpose and leave as whole 64-byte rows.
 #define YH_BUCKET_MAX_KEYS 65536u
-struct BucketWideArgs {
-    BucketArgs b;
-    uint32_t n_slices;  // power of two, a multiple of 256 (4 waves per workgroup: n_slices / 4 workgroups)
-};
-
-__device__ __forceinline__ void bucket_wave_slice(const BucketWideArgs& a, uint32_t slice, uint64_t& lo, uint64_t& hi) {
-    uint64_t count = *a.b.count_ptr;
-    if (count > a.b.cap) count = a.b.cap;
+__device__ __forceinline__ void bucket_wave_slice(const BucketArgs& a, uint32_t slice, uint64_t& lo, uint64_t& hi) {
+    uint64_t count = *a.count_ptr;
+    if (count > a.cap) count = a.cap;
     uint64_t per = (count + a.n_slices - 1) / a.n_slices;
     per = (per + 63u) & ~63ull;
     lo = (uint64_t)slice * per;
@@ -1291,10 +1319,11 @@ __device__ __forceinline__ void bucket_wave_slice(const BucketWideArgs& a, uint3
 
 // rank of this lane among the wave's active lanes with the same key (lane order), their number, and whether this lane
 // is the first of them: one turn per distinct key
-__device__ __forceinline__ void match_keys(bool active, uint32_t key, uint32_t& rank, uint32_t& same_count, bool& first) {
+__device__ __forceinline__ void match_keys(bool active, uint32_t key, uint32_t& rank, uint32_t& same_count, bool& first, uint32_t& leader_lane) {
     rank = 0;
     same_count = 0;
     first = false;
+    leader_lane = threadIdx.x & 63u;
     uint64_t todo = __ballot(active);
     while (todo) {
         const int leader = __ffsll((unsigned long long)todo) - 1;
@@ -1304,107 +1333,56 @@ __device__ __forceinline__ void match_keys(bool active, uint32_t key, uint32_t& 
             rank = lane_rank(same);
             same_count = (uint32_t)__popcll(same);
             first = (int)(threadIdx.x & 63u) == leader;
+            leader_lane = (uint32_t)leader;
         }
         todo &= ~same;
     }
 }
 
-__global__ __launch_bounds__(YH_BLOCK) void k_bucketw_hist(BucketWideArgs a) {
+__global__ __launch_bounds__(YH_BLOCK) void k_bucketw_hist(BucketArgs a) {
     const uint32_t slice = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     uint64_t lo, hi;
     bucket_wave_slice(a, slice, lo, hi);
     for (uint64_t i0 = lo; i0 < hi; i0 += 64u) {  // wave-uniform
         const bool active = i0 + lane < hi;
-        const uint32_t key = active ? a.b.mesh_id[a.b.list[i0 + lane] - a.b.id_base] : 0u;
-        uint32_t rank, cnt;
+        const uint32_t key = active ? a.mesh_id[a.list[i0 + lane] - a.id_base] : 0u;
+        uint32_t rank, cnt, leader;
         bool first;
-        match_keys(active, key, rank, cnt, first);
-        if (first) atomicAdd(&a.b.hist[(uint64_t)key * a.n_slices + slice], cnt);  // (this wave's own counter: ordering, not contention)
+        match_keys(active, key, rank, cnt, first, leader);
+        if (first) atomicAdd(&a.hist[(uint64_t)key * a.n_slices + slice], cnt);  // (this wave's own counter: ordering, not contention)
     }
 }
 
-// One workgroup per key: exclusive scan of the row's n_slices counts, total to totals[key].
-__global__ __launch_bounds__(YH_BLOCK) void k_bucket_rows_n(BucketWideArgs a) {
-    __shared__ uint32_t part[YH_BLOCK];
-    const uint32_t per = a.n_slices / YH_BLOCK;  // 1 .. 64 consecutive values per thread
-    uint32_t* row = a.b.hist + (uint64_t)blockIdx.x * a.n_slices + threadIdx.x * per;
-    uint32_t sum = 0;
-    for (uint32_t i = 0; i < per; ++i) sum += row[i];
-    const uint32_t inc = block_scan_256(sum, part);
-    uint32_t run = inc - sum;
-    for (uint32_t i = 0; i < per; ++i) {
-        const uint32_t v = row[i];
-        row[i] = run;
-        run += v;
-    }
-    if (threadIdx.x == YH_BLOCK - 1) a.b.totals[blockIdx.x] = inc;
-}
-
-// One workgroup: bucket starts = exclusive scan of all keys' totals, 256 at a time with a carry; the bucket table.
-__global__ __launch_bounds__(YH_BLOCK) void k_bucket_starts_n(BucketWideArgs a) {
-    __shared__ uint32_t part[YH_BLOCK];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t m0 = 0; m0 < a.b.n_meshes; m0 += YH_BLOCK) {
-        const uint32_t m = m0 + threadIdx.x;
-        const uint32_t total = m < a.b.n_meshes ? a.b.totals[m] : 0u;
-        const uint32_t inc = block_scan_256(total, part);
-        const uint32_t before = carry;
-        if (m < a.b.n_meshes) {
-            const uint32_t first = before + inc - total;
-            a.b.starts[m] = first;
-            a.b.buckets[3 * m + 0] = m;
-            a.b.buckets[3 * m + 1] = first;
-            a.b.buckets[3 * m + 2] = total;
-        }
-        __syncthreads();
-        if (threadIdx.x == YH_BLOCK - 1) carry = before + inc;
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(YH_BLOCK) void k_bucketw_scatter(BucketWideArgs a) {
+__global__ __launch_bounds__(YH_BLOCK) void k_bucketw_scatter(BucketArgs a) {
     __shared__ uint32_t rows[4][64 * 17];  // one transpose area per wave: nothing is shared between waves, no workgroup barrier
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t slice = blockIdx.x * 4u + wave;
     uint32_t* __restrict__ mine = rows[wave];
     uint64_t lo, hi;
     bucket_wave_slice(a, slice, lo, hi);
-    uint32_t id_n = lo + lane < hi ? a.b.list[lo + lane] : a.b.id_base;
+    uint32_t id_n = lo + lane < hi ? a.list[lo + lane] : a.id_base;
     for (uint64_t i0 = lo; i0 < hi; i0 += 64u) {  // wave-uniform
         const bool active = i0 + lane < hi;
         const uint32_t id = id_n;
-        id_n = i0 + 64u + lane < hi ? a.b.list[i0 + 64u + lane] : a.b.id_base;  // the next entries, on their way
-        const uint32_t e = id - a.b.id_base;
-        const uint32_t key = active ? a.b.mesh_id[e] : 0u;
+        id_n = i0 + 64u + lane < hi ? a.list[i0 + 64u + lane] : a.id_base;  // the next entries, on their way
+        const uint32_t e = id - a.id_base;
+        const uint32_t key = active ? a.mesh_id[e] : 0u;
         float w[16];
         {
             const uint64_t off = eoff<16>(e);  // (an inactive lane reads entity 0's row: in bounds)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) w[q] = lde(a.b.world, off, q);
+            for (int q = 0; q < 16; ++q) w[q] = lde(a.world, off, q);
         }
-        uint32_t rank, cnt;
+        uint32_t rank, cnt, leader;
         bool first;
-        match_keys(active, key, rank, cnt, first);
+        match_keys(active, key, rank, cnt, first, leader);
         uint32_t base = 0;
-        if (first) base = atomicAdd(&a.b.hist[(uint64_t)key * a.n_slices + slice], cnt);  // running offset of (key, slice)
-        // every lane takes its key's base from the first lane of that key
-        uint32_t pos = 0;
-        {
-            uint64_t todo = __ballot(active);
-            while (todo) {
-                const int leader = __ffsll((unsigned long long)todo) - 1;
-                const uint32_t lk = __shfl(key, leader);
-                const uint32_t lb = __shfl(base, leader);
-                const uint64_t same = __ballot(active && key == lk);
-                if (active && key == lk) pos = a.b.starts[key] + lb + rank;
-                todo &= ~same;
-            }
-        }
+        if (first) base = atomicAdd(&a.hist[(uint64_t)key * a.n_slices + slice], cnt);  // running offset of (key, slice)
+        base = (uint32_t)__shfl((int)base, (int)leader);  // every lane takes its key's base from the first lane of that key
+        const uint32_t pos = active ? a.starts[key] + base + rank : 0u;
         if (active) {
-            a.b.out_list[pos] = id;
-            a.b.cmds[pos] = make_uint4(a.b.vcount ? a.b.vcount[key] : 0u, 1u, 0u, a.b.batch_offset + pos);
+            a.out_list[pos] = id;
+            a.cmds[pos] = make_uint4(a.vcount ? a.vcount[key] : 0u, 1u, 0u, a.batch_offset + pos);
         }
         __builtin_amdgcn_wave_barrier();  // (the wave's earlier reads of `mine` stay ahead of these writes)
 #pragma unroll
@@ -1416,7 +1394,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucketw_scatter(BucketWideArgs a) 
         for (uint32_t k = 0; k < 16u; ++k) {
             const uint32_t r = 4u * k + (lane >> 4);
             const uint32_t rp = (uint32_t)__shfl((int)pos, (int)r);
-            if (r < n_tile) a.b.obj[(uint64_t)rp * 16 + (lane & 15u)] = mine[r * 17 + (lane & 15u)];
+            if (r < n_tile) a.obj[(uint64_t)rp * 16 + (lane & 15u)] = mine[r * 17 + (lane & 15u)];
         }
     }
 }

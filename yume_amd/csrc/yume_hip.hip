@@ -1795,10 +1795,19 @@ extern "C" int yh_build_mesh_buckets(yh_scene* s, uint32_t frustum, uint32_t bat
     // scene): one slice per WAVE, counters in global memory only, keys x slices kept within 16M counters.
     const uint32_t M = std::min<uint32_t>(std::max<uint32_t>(s->desc.max_meshes, 1u), YH_BUCKET_MAX_KEYS);
     const bool wide = s->n_meshes > YH_BUCKET_MAX_MESHES || getenv("YH_BUCKET_WIDE") != nullptr;  // (the knob: A/B runs of the two paths)
-    uint32_t slices = YH_BUCKET_SLICES;
+    // Slices the list is cut into.  Few keys: up to 32768 workgroup slices of at least four 256-entry tiles each, keys x
+    // slices within 4M counters (64M instances / 16 keys: 4096 slices 1.945 ms, 32768 1.898, one slice per tile - 250k -
+    // 2.448: the scans over the slices grow; profiles/r03/bucket_slices.txt).  Many keys: one slice per wave, <= 16384.
+    uint32_t slices;
     if (wide) {
         slices = 16384u;
         while (slices > 256u && (uint64_t)slices * s->n_meshes > (16ull << 20)) slices >>= 1;
+    } else {
+        const uint64_t tiles = (std::min<uint64_t>(s->draw_cap, s->n) + YH_BLOCK - 1) / YH_BLOCK;
+        const uint64_t room = (4ull << 20) / s->n_meshes;
+        slices = (uint32_t)std::max<uint64_t>(std::min<uint64_t>(std::min<uint64_t>(tiles / 4, 32768), room), 256);
+        if (const char* v = getenv("YH_BUCKET_SLICES")) slices = (uint32_t)strtoul(v, nullptr, 10);  // (A/B runs)
+        slices = (slices + 255u) & ~255u;
     }
     if (!s->blist[frustum]) {
         HIP_TRY(ctx, hipMalloc((void**)&s->blist[frustum], s->draw_cap * 4));
@@ -1833,25 +1842,17 @@ extern "C" int yh_build_mesh_buckets(yh_scene* s, uint32_t frustum, uint32_t bat
     a.out_list = s->blist[frustum];
     a.obj = s->obj[frustum];
     a.cmds = s->cmd[frustum];
+    a.n_slices = slices;
     if (wide) {
-        BucketWideArgs w{};
-        w.b = a;
-        w.n_slices = slices;
         HIP_TRY(ctx, hipMemsetAsync(a.hist, 0, (uint64_t)s->n_meshes * slices * 4, ctx->stream));
-        hipLaunchKernelGGL(k_bucketw_hist, dim3(slices / 4), dim3(YH_BLOCK), 0, ctx->stream, w);
-        hipLaunchKernelGGL(k_bucket_rows_n, dim3(s->n_meshes), dim3(YH_BLOCK), 0, ctx->stream, w);
-        hipLaunchKernelGGL(k_bucket_starts_n, dim3(1), dim3(YH_BLOCK), 0, ctx->stream, w);
-        hipLaunchKernelGGL(k_bucketw_scatter, dim3(slices / 4), dim3(YH_BLOCK), 0, ctx->stream, w);
-        HIP_TRY(ctx, hipGetLastError());
-        s->frame_pending = true;
-        s->bucketed[frustum] = true;
-        return YH_OK;
+        hipLaunchKernelGGL(k_bucketw_hist, dim3(slices / 4), dim3(YH_BLOCK), 0, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL(k_bucket_hist, dim3(slices), dim3(YH_BLOCK), 0, ctx->stream, a);
     }
-    const dim3 grid(YH_BUCKET_SLICES);
-    hipLaunchKernelGGL(k_bucket_hist, grid, dim3(YH_BLOCK), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_bucket_rows, dim3(s->n_meshes), dim3(YH_BLOCK), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_bucket_starts, dim3(1), dim3(YH_BLOCK), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k_bucket_scatter, grid, dim3(YH_BLOCK), 0, ctx->stream, a);
+    if (wide) hipLaunchKernelGGL(k_bucketw_scatter, dim3(slices / 4), dim3(YH_BLOCK), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_bucket_scatter, dim3(slices), dim3(YH_BLOCK), 0, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
     s->frame_pending = true;
     s->bucketed[frustum] = true;
