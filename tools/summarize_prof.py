@@ -5,7 +5,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out_dir = os.path.join("profiles", rnd)
 os.makedirs(out_dir, exist_ok=True)
 lines = [f"# rocprofv3 evidence, round {rnd[1:]}", "",
-         "Collected on one MI355X (gfx950) with `tools/profile_r02.sh`: `default` is the driver's own command (`python3 bench.py`,",
+         f"Collected on one MI355X (gfx950) with `tools/profile_{rnd}.sh`: `default` is the driver's own command (`python3 bench.py`,",
          "CPU leg off) under `--kernel-trace --stats`; per workload `tools/profile.sh <workload>` = one `--kernel-trace --stats` run of",
          "`bench.py --workload <w> --no-sub --steps 400 --warmup 20`, then separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs",
          "(20 steps).  Counter units are KiB per dispatch.  gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE",
