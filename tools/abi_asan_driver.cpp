@@ -1,4 +1,4 @@
-// Host-side sanitizer run of the C ABI (include/yume_hip.h): this file and yume_amd/csrc/yume_hip.hip are compiled
+// Host-side sanitizer run of the C ABI (include/yume_hip.h): this file and the library's translation units (yume_amd/csrc/yh_*.hip) are compiled
 // into ONE executable with AddressSanitizer + UBSan on the host code only (make -C yume_amd/csrc asan_driver; the
 // device code is unchanged), and the calls below walk the library's host paths: scene set-up, uploads, frames of both
 // scene kinds, lists, consumers, buckets, change tracking, decompose, the gather self-test, a one-rank RCCL gather, error returns.

@@ -1,13 +1,17 @@
 // A/B: a cfg2-like scene's frames (two dependent launches each, ~33 us) enqueued one by one against the same frames
 // replayed from a hipGraph (64 frames captured on the library's stream - the ring of boundary-counter sets and the two
-// sets of visibility words come round after 64 - and launched 32 times).  One translation unit with the library so
-// that the context's stream is in reach; not part of the product.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fno-vectorize -o tools/bin/graph_probe tools/graph_probe.hip -ldl
+// sets of visibility words come round after 64 - and launched 32 times).  Links the library; the context's stream comes
+// from yh_stream().  Not part of the product.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -o tools/bin/graph_probe tools/graph_probe.hip -Lyume_amd -lyume_hip -Wl,-rpath,$PWD/yume_amd
 #include <chrono>
 #include <cstdio>
 #include <vector>
 
-#include "../yume_amd/csrc/yume_hip.hip"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "yume_hip.h"
 
 #define CK(call)                                                                                       \
     do {                                                                                               \
@@ -70,19 +74,19 @@ int main(int argc, char** argv) {
         CK(yh_frame(s, planes, 1, flags));
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return 2;
+        if (hipStreamBeginCapture((hipStream_t)yh_stream(ctx), hipStreamCaptureModeThreadLocal) != hipSuccess) return 2;
         for (int i = 0; i < PER_GRAPH; ++i) CK(yh_frame(s, planes, 1, flags));
-        if (hipStreamEndCapture(ctx->stream, &graph) != hipSuccess) return 3;
+        if (hipStreamEndCapture((hipStream_t)yh_stream(ctx), &graph) != hipSuccess) return 3;
         if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) return 4;
         size_t nodes = 0;
         (void)hipGraphGetNodes(graph, nullptr, &nodes);
         for (int i = 0; i < 4; ++i)
-            if (hipGraphLaunch(exec, ctx->stream) != hipSuccess) return 5;
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return 6;
+            if (hipGraphLaunch(exec, (hipStream_t)yh_stream(ctx)) != hipSuccess) return 5;
+        if (hipStreamSynchronize((hipStream_t)yh_stream(ctx)) != hipSuccess) return 6;
         t0 = now_us();
         for (int i = 0; i < FRAMES / PER_GRAPH; ++i)
-            if (hipGraphLaunch(exec, ctx->stream) != hipSuccess) return 5;
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return 6;
+            if (hipGraphLaunch(exec, (hipStream_t)yh_stream(ctx)) != hipSuccess) return 5;
+        if (hipStreamSynchronize((hipStream_t)yh_stream(ctx)) != hipSuccess) return 6;
         const double replay = (now_us() - t0) / FRAMES;
         CK(yh_get_counts(s, counts, bc));  // (flushes the last captured frame's pending expansion)
         printf("n=%u: eager %.2f us per frame, hipGraph replay (%d frames, %zu nodes per graph) %.2f us per frame; visible %u / %u\n", n,

@@ -18,6 +18,11 @@
 // 64 consecutive children gather from a short contiguous run of parent chunks.
 //
 // All kernels are HBM-bound streaming kernels: one entity per lane, no MFMA.
+//
+// The library is built from several translation units (yh_internal.hpp); argument structs, inline device functions and
+// kernel TEMPLATES are visible to all of them, a plain __global__ kernel is compiled into the one unit that asks for
+// its group before including this header: YH_K_FRAME (yh_frame.hip), YH_K_SCENE (yh_scene.hip), YH_K_CONSUMERS
+// (yh_consumers.hip), YH_K_GATHER (yh_comm.hip).
 #pragma once
 #include <utility>
 
@@ -761,6 +766,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_chain_mat4(const FrameArgs a, cons
     if (BOUNDS != 0) publish_visible(a, (uint32_t)(e64 >> 6), e64 - (tid & 63u) < a.begin, vmask, bmask);
 }
 
+#ifdef YH_K_FRAME
 // Tile bases of the expansion, from the popcount BYTES the frame kernels left next to the words: one workgroup per
 // segment of 4096 words (16 bytes = one load per thread), grid = (segments, frusta).  Writes, per tile, the entries of
 // its segment before it, and per segment its entries: an expand workgroup then adds up the segments before its own (at
@@ -800,6 +806,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_count(const ExpandArgs x) {
 
 // grid = (n_tiles, frusta)
 __global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) { expand_tile(x, blockIdx.x, blockIdx.y); }
+#endif  // YH_K_FRAME
 
 // The same sweep when changes are tracked (yh_scene_track_changes): one wave per 64-entity chunk first publishes two
 // ballots as the chunk's words of the two change masks, then clears both flags.
@@ -815,6 +822,7 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {  // bit i = byte
     const uint32_t t = ((x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u) >> 7;
     return (t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu;
 }
+#ifdef YH_K_FRAME
 __global__ __launch_bounds__(YH_BLOCK) void k_sweep_dirty(uint8_t* __restrict__ ld, uint8_t* __restrict__ wd, uint32_t n,
                                                           uint64_t* __restrict__ words, uint8_t* __restrict__ counts,
                                                           uint32_t n_chunks, uint32_t cnt_stride,
@@ -867,7 +875,9 @@ __global__ __launch_bounds__(YH_BLOCK) void k_zero_sets(uint32_t* __restrict__ s
     const uint32_t t = threadIdx.x;  // YH_BLOCK threads = 32 sets of YH_K_MAX_FRUSTA (8) words
     if (t < n_sets * 8u) sets[((first + t / 8u) % ring) * 8u + (t & 7u)] = 0u;
 }
+#endif  // YH_K_FRAME
 
+#ifdef YH_K_SCENE
 __global__ __launch_bounds__(YH_BLOCK) void k_fill_u8(uint8_t* __restrict__ p, uint8_t v, uint64_t first, uint64_t count) {
     const uint64_t i = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;
     if (i < count) p[first + i] = v;
@@ -985,6 +995,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_soa_to_aos68(const float* __restri
     const uint64_t ndw = nrows * 17;
     for (uint32_t i = threadIdx.x; i < ndw; i += YH_BLOCK) rows[r0 * 17 + i] = tile[i];
 }
+#endif  // YH_K_SCENE
 
 // Multi-GPU, no-host-sync gather.  What crosses xGMI is the visibility WORDS, not the lists: one bit per entity
 // instead of four bytes per visible entity (32x fewer bytes than lists padded to capacity, and a fixed size, so a
@@ -1002,6 +1013,7 @@ struct GatherArgs {
     uint32_t tile_words;  // words per tile: 64, or 256 for long rows (as k_expand)
 };
 
+#ifdef YH_K_GATHER
 __global__ __launch_bounds__(YH_BLOCK) void k_gather_count(const GatherArgs g) {
     __shared__ uint32_t s_red[4];
     const uint32_t t = blockIdx.x, f = blockIdx.y, r = blockIdx.z;
@@ -1042,7 +1054,9 @@ __global__ __launch_bounds__(YH_BLOCK) void k_gather_expand(const GatherArgs g) 
     const uint32_t pos = __builtin_amdgcn_readfirstlane(base + before);
     expand_run(g.out[f] + pos, (uint32_t)m, (uint32_t)(m >> 32), n_words, (cw << 6) + lane + g.peer[r * 4 + 1]);
 }
+#endif  // YH_K_GATHER
 
+#ifdef YH_K_CONSUMERS
 // ---------------------------------------------------------------------------------------------------
 // Draw-list consumer: what the reference's draw loop does on the CPU for every object it is handed
 // (GAL/vulkan/RenderApi.zig:1397-1404: object_data_arr[batch_offset + index] = GPUObjectData{model_matrix};
@@ -1072,6 +1086,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_build_objects(const float* __restr
     const uint32_t ndw = (uint32_t)nrows * 16u;
     for (uint32_t i = threadIdx.x; i < ndw; i += YH_BLOCK) obj[r0 * 16 + i] = tile[(i >> 4) * 17 + (i & 15u)];
 }
+#endif  // YH_K_CONSUMERS
 
 // ---------------------------------------------------------------------------------------------------
 // Per-mesh bucketing of a draw list.  The reference's draw loop rebinds the vertex buffer
@@ -1114,6 +1129,7 @@ __device__ __forceinline__ void bucket_slice(const BucketArgs& a, uint32_t slice
     if (hi > count) hi = count;
 }
 
+#ifdef YH_K_CONSUMERS
 __global__ __launch_bounds__(YH_BLOCK) void k_bucket_hist(BucketArgs a) {
     __shared__ uint32_t h[YH_BUCKET_MAX_MESHES];
     for (uint32_t m = threadIdx.x; m < a.n_meshes; m += YH_BLOCK) h[m] = 0;
@@ -1124,6 +1140,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_hist(BucketArgs a) {
     __syncthreads();
     for (uint32_t m = threadIdx.x; m < a.n_meshes; m += YH_BLOCK) a.hist[(uint64_t)m * a.n_slices + blockIdx.x] = h[m];
 }
+#endif  // YH_K_CONSUMERS
 
 // Inclusive scan of one value per thread over the workgroup (256 threads): inside each wave by lane shuffles, the four
 // wave totals through LDS (two barriers instead of the seventeen of a scan that steps through LDS; ends with a barrier).
@@ -1160,6 +1177,7 @@ __device__ __forceinline__ uint32_t block_scan_256_lds(uint32_t v, uint32_t* par
     return before + inc;
 }
 
+#ifdef YH_K_CONSUMERS
 // One workgroup per key: exclusive scan of the row's n_slices counts (n_slices / 256 consecutive values per thread),
 // total to totals[key].
 __global__ __launch_bounds__(YH_BLOCK) void k_bucket_rows(BucketArgs a) {
@@ -1295,6 +1313,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
         for (int q = 0; q < 16; ++q) w_c[q] = w_n[q];
     }
 }
+#endif  // YH_K_CONSUMERS
 
 // ---- the same for MANY keys (257 .. YH_BUCKET_MAX_KEYS: one key per (material, mesh) pair of a scene) ------------------
 // With thousands of keys a 256-entry tile holds a key once or not at all, so there is nothing to sort inside a tile and
@@ -1339,6 +1358,7 @@ __device__ __forceinline__ void match_keys(bool active, uint32_t key, uint32_t& 
     }
 }
 
+#ifdef YH_K_CONSUMERS
 __global__ __launch_bounds__(YH_BLOCK) void k_bucketw_hist(BucketArgs a) {
     const uint32_t slice = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     uint64_t lo, hi;
@@ -1398,7 +1418,9 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucketw_scatter(BucketArgs a) {
         }
     }
 }
+#endif  // YH_K_CONSUMERS
 
+#ifdef YH_K_SCENE
 // ---------------------------------------------------------------------------------------------------
 // Synthetic scene generator: TRS + bounds from the counter-based hash, bit-identical to
 // the oracle's host generator.  Level 0 (local index < n_level0) draws from the wide ranges.
@@ -1444,3 +1466,4 @@ __global__ __launch_bounds__(YH_BLOCK) void k_synth(float* __restrict__ trs, flo
     }
     if (mesh_id) mesh_id[e] = (uint32_t)(yh_synth_raw(seed, 13, g) >> 32) % n_meshes;
 }
+#endif  // YH_K_SCENE

@@ -297,7 +297,7 @@ YH_HD uint32_t cull_frustum(const M4& m, const CullBox& b, const float* __restri
 //     s = ((a*cwx + b*cwy) + c*cwz) + d   = p(n) + d          r = r(n)          t = s + r
 // and for the opposite normal -n both p and r come out as exactly -p and r (IEEE negation is exact and rounding is
 // symmetric; only the sign of a zero can differ, which no comparison below sees).  The host groups the frame's planes
-// by normal (yume_hip.hip build_cull_plan): per distinct normal one evaluation of p and r, per plane
+// by normal (yh_frame.hip build_cull_plan): per distinct normal one evaluation of p and r, per plane
 // t = fma(sgn, p, d) + r with sgn = +-1 — the product is exact, so the fused form rounds once, exactly like
 // (sgn*p) + d — and the two comparisons.  Bit for bit the visible / boundary flags of cull_frustum on every plane.
 struct CullPlanNormal {
