@@ -78,7 +78,8 @@ extern "C" int yh_build_mesh_buckets(yh_scene* s, uint32_t frustum, uint32_t bat
         HIP_TRY(ctx, hipMalloc((void**)&s->blist[frustum], s->draw_cap * 4));
         HIP_TRY(ctx, hipMalloc((void**)&s->bkt[frustum], (uint64_t)M * 12));
     }
-    const uint64_t scratch_words = (uint64_t)s->n_meshes * slices + 2ull * M;
+    const uint32_t n_seg = (slices + YH_BUCKET_SEG - 1u) / YH_BUCKET_SEG;
+    const uint64_t scratch_words = (uint64_t)s->n_meshes * slices + 2ull * M + (uint64_t)s->n_meshes * n_seg;
     if (scratch_words > s->bscratch_words) {  // (the mesh table grew, or went from few keys to many)
         if (s->bscratch) {
             if (int rc = sync_scene(s)) return rc;
@@ -100,6 +101,8 @@ extern "C" int yh_build_mesh_buckets(yh_scene* s, uint32_t frustum, uint32_t bat
     a.hist = s->bscratch;
     a.totals = s->bscratch + (uint64_t)s->n_meshes * slices;
     a.starts = a.totals + M;
+    a.segtot = a.starts + M;
+    a.n_seg = n_seg;
     a.buckets = s->bkt[frustum];
     a.world = s->world;
     a.vcount = s->vcount;
@@ -114,8 +117,9 @@ extern "C" int yh_build_mesh_buckets(yh_scene* s, uint32_t frustum, uint32_t bat
     } else {
         hipLaunchKernelGGL(k_bucket_hist, dim3(slices), dim3(YH_BLOCK), 0, ctx->stream, a);
     }
-    hipLaunchKernelGGL(k_bucket_rows, dim3(s->n_meshes), dim3(YH_BLOCK), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_bucket_segsum, dim3(s->n_meshes * n_seg), dim3(YH_BLOCK), 0, ctx->stream, a);
     hipLaunchKernelGGL(k_bucket_starts, dim3(1), dim3(YH_BLOCK), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_bucket_rows, dim3(s->n_meshes * n_seg), dim3(YH_BLOCK), 0, ctx->stream, a);
     if (wide) hipLaunchKernelGGL(k_bucketw_scatter, dim3(slices / 4), dim3(YH_BLOCK), 0, ctx->stream, a);
     else hipLaunchKernelGGL(k_bucket_scatter, dim3(slices), dim3(YH_BLOCK), 0, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());

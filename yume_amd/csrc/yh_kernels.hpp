@@ -1108,6 +1108,8 @@ struct BucketArgs {
     uint32_t n_slices; // slices the list is cut into (a multiple of 256, chosen by the host)
     uint32_t* hist;    // [n_meshes][n_slices] counts, then (k_bucket_rows) exclusive offsets inside the row
     uint32_t* totals;  // [n_meshes]
+    uint32_t* segtot;  // [n_meshes][n_seg] totals of the row's segments of YH_BUCKET_SEG slices, then their exclusive prefix
+    uint32_t n_seg;
     uint32_t* starts;  // [n_meshes] first output position of each bucket
     uint32_t* buckets; // [n_meshes] x {mesh, first, count}
     const float* world;
@@ -1178,26 +1180,29 @@ __device__ __forceinline__ uint32_t block_scan_256_lds(uint32_t v, uint32_t* par
 }
 
 #ifdef YH_K_CONSUMERS
-// One workgroup per key: exclusive scan of the row's n_slices counts (n_slices / 256 consecutive values per thread),
-// total to totals[key].
-__global__ __launch_bounds__(YH_BLOCK) void k_bucket_rows(BucketArgs a) {
-    __shared__ uint32_t part[YH_BLOCK];
-    const uint32_t per = a.n_slices / YH_BLOCK;
-    uint32_t* row = a.hist + (uint64_t)blockIdx.x * a.n_slices + threadIdx.x * per;
+// hist[key][slice] -> exclusive offsets inside the key's row, in three small launches that use the whole chip whatever
+// the number of keys (one workgroup per key left 16 keys x 32768 slices to 16 workgroups: 59 us; 124 us at 4096 keys):
+// k_bucket_segsum   one workgroup per (key, segment of YH_BUCKET_SEG slices): the segment's total;
+// k_bucket_starts   one workgroup: per key the exclusive prefix over its segments and its total, then the exclusive scan
+//                   of the totals = the buckets' first positions, and the bucket table the renderer reads;
+// k_bucket_rows     one workgroup per (key, segment) again: exclusive scan inside the segment + the segment's prefix.
+// Eight consecutive slices per thread (two 16-byte loads; n_slices is a multiple of 256, so a thread's eight are all
+// inside the row or all outside).
+#define YH_BUCKET_SEG 2048u
+__global__ __launch_bounds__(YH_BLOCK) void k_bucket_segsum(BucketArgs a) {
+    __shared__ uint32_t s_red[4];
+    const uint32_t key = blockIdx.x / a.n_seg, seg = blockIdx.x - key * a.n_seg;
+    const uint32_t s0 = seg * YH_BUCKET_SEG + threadIdx.x * 8u;
     uint32_t sum = 0;
-    for (uint32_t i = 0; i < per; ++i) sum += row[i];
-    const uint32_t inc = block_scan_256(sum, part);
-    uint32_t run = inc - sum;
-    for (uint32_t i = 0; i < per; ++i) {
-        const uint32_t v = row[i];
-        row[i] = run;
-        run += v;
+    if (s0 < a.n_slices) {
+        const uint4* p = reinterpret_cast<const uint4*>(a.hist + (uint64_t)key * a.n_slices + s0);
+        const uint4 u = p[0], v = p[1];
+        sum = u.x + u.y + u.z + u.w + v.x + v.y + v.z + v.w;
     }
-    if (threadIdx.x == YH_BLOCK - 1) a.totals[blockIdx.x] = inc;
+    const uint32_t total = block_sum_256(sum, s_red);
+    if (threadIdx.x == 0) a.segtot[blockIdx.x] = total;
 }
 
-// One workgroup: bucket starts = exclusive scan of all keys' totals, 256 at a time with a carry; the bucket table the
-// renderer reads.
 __global__ __launch_bounds__(YH_BLOCK) void k_bucket_starts(BucketArgs a) {
     __shared__ uint32_t part[YH_BLOCK];
     __shared__ uint32_t carry;
@@ -1205,11 +1210,18 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_starts(BucketArgs a) {
     __syncthreads();
     for (uint32_t m0 = 0; m0 < a.n_meshes; m0 += YH_BLOCK) {
         const uint32_t m = m0 + threadIdx.x;
-        const uint32_t total = m < a.n_meshes ? a.totals[m] : 0u;
+        uint32_t total = 0;
+        if (m < a.n_meshes)
+            for (uint32_t g = 0; g < a.n_seg; ++g) {
+                const uint32_t v = a.segtot[(uint64_t)m * a.n_seg + g];
+                a.segtot[(uint64_t)m * a.n_seg + g] = total;
+                total += v;
+            }
         const uint32_t inc = block_scan_256(total, part);
         const uint32_t before = carry;
         if (m < a.n_meshes) {
             const uint32_t first = before + inc - total;
+            a.totals[m] = total;
             a.starts[m] = first;
             a.buckets[3 * m + 0] = m;
             a.buckets[3 * m + 1] = first;
@@ -1221,41 +1233,69 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_starts(BucketArgs a) {
     }
 }
 
+__global__ __launch_bounds__(YH_BLOCK) void k_bucket_rows(BucketArgs a) {
+    __shared__ uint32_t part[YH_BLOCK];
+    const uint32_t key = blockIdx.x / a.n_seg, seg = blockIdx.x - key * a.n_seg;
+    const uint32_t s0 = seg * YH_BUCKET_SEG + threadIdx.x * 8u;
+    const bool in = s0 < a.n_slices;
+    uint4* p = reinterpret_cast<uint4*>(a.hist + (uint64_t)key * a.n_slices + (in ? s0 : 0u));
+    uint4 u = make_uint4(0, 0, 0, 0), v = u;
+    if (in) u = p[0], v = p[1];
+    const uint32_t sum = u.x + u.y + u.z + u.w + v.x + v.y + v.z + v.w;
+    const uint32_t inc = block_scan_256(sum, part);
+    uint32_t run = a.segtot[blockIdx.x] + inc - sum;
+    if (in) {
+        uint4 o, q;
+        o.x = run, run += u.x;
+        o.y = run, run += u.y;
+        o.z = run, run += u.z;
+        o.w = run, run += u.w;
+        q.x = run, run += v.x;
+        q.y = run, run += v.y;
+        q.z = run, run += v.z;
+        q.w = run;
+        p[0] = o, p[1] = q;
+    }
+}
+
 __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
     __shared__ uint32_t base[YH_BUCKET_MAX_MESHES];        // next output position of each bucket, for this slice
     __shared__ uint32_t wcnt[4][YH_BUCKET_MAX_MESHES];     // entries of each mesh in each wave's 64, then wave offsets
     __shared__ uint32_t lstart[YH_BUCKET_MAX_MESHES];      // first tile-local sorted index of each mesh
+    __shared__ uint32_t s_vcount[YH_BUCKET_MAX_MESHES];    // the vertex-count table (no gather from memory inside a tile)
     __shared__ uint32_t part[YH_BLOCK];
     __shared__ uint32_t s_pos[YH_BLOCK], s_id[YH_BLOCK], s_vc[YH_BLOCK];  // the tile in bucket order
     __shared__ uint32_t rows[YH_BLOCK * 17];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    for (uint32_t m = tid; m < a.n_meshes; m += YH_BLOCK) base[m] = a.starts[m] + a.hist[(uint64_t)m * a.n_slices + blockIdx.x];
+    for (uint32_t m = tid; m < a.n_meshes; m += YH_BLOCK) {
+        base[m] = a.starts[m] + a.hist[(uint64_t)m * a.n_slices + blockIdx.x];
+        s_vcount[m] = a.vcount ? a.vcount[m] : 0u;
+    }
     uint64_t lo, hi;
     bucket_slice(a, blockIdx.x, lo, hi);
-    // Two-stage software pipeline over the slice's tiles: while tile k is sorted and written, the rows and mesh ids of
-    // tile k + 1 are in flight (their list entries were loaded during tile k - 1) and so are the list entries of tile
-    // k + 2 - plain loads survive the barriers below.  Without it every tile waited for a dependent chain of three
-    // gathers (list entry -> mesh id, matrix row) before its first barrier.
-    uint32_t id_c = lo + tid < hi ? a.list[lo + tid] : a.id_base;
-    uint32_t id_n = lo + YH_BLOCK + tid < hi ? a.list[lo + YH_BLOCK + tid] : a.id_base;
-    uint32_t m_c = lo + tid < hi ? a.mesh_id[id_c - a.id_base] : 0xFFFFFFFFu;
-    float w_c[16];
+    // Software pipeline over the slice's tiles with ONE set of row registers and no register copies: a tile's rows are
+    // loaded right after the tile before it has been staged in LDS (the registers are free again) and BEFORE that tile's
+    // stores are issued, its list entries one tile earlier still.  Everything in the loop body is straight-line code
+    // with a fixed number of loads and stores (the sixteen row stores are unrolled and predicated, not a loop), so the
+    // compiler waits for exactly the loads it needs (s_waitcnt vmcnt(n), n = what was issued after them) and a tile's
+    // scattered stores stay in flight while the next tile is sorted.  (Before: a register copy at the loop's end and a
+    // store loop of unknown length each cost an s_waitcnt vmcnt(0) per tile, i.e. every tile waited for the
+    // acknowledgement of its own stores.  It bought 1 %: the pass is bound elsewhere, profiles/r03/bucket_slices.txt.)
+    // (No load or store below sits behind a branch: a lane past the slice's end re-reads the slice's last entry and
+    // re-writes the tile's last row - the same value to the same address - so the counts stay fixed on every path.)
+    if (lo >= hi) return;  // (whole workgroup)
+    const uint64_t last = hi - 1;
+    uint32_t id_c = a.list[min(lo + tid, last)];
+    uint32_t id_n = a.list[min(lo + YH_BLOCK + tid, last)];
+    uint32_t m_c = a.mesh_id[id_c - a.id_base];
+    float w[16];
     {
         const uint64_t off = eoff<16>(id_c - a.id_base);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) w_c[q] = lde(a.world, off, q);
+        for (int q = 0; q < 16; ++q) w[q] = lde(a.world, off, q);
     }
-    for (uint64_t i0 = lo; i0 < hi; i0 += YH_BLOCK) {  // uniform trip count for the workgroup
+    auto tile = [&](const uint64_t i0) __attribute__((always_inline)) {
         const uint32_t n_tile = (uint32_t)((hi - i0 < YH_BLOCK) ? (hi - i0) : YH_BLOCK);
-        const bool next_active = i0 + YH_BLOCK + tid < hi;
-        const uint32_t m_n = next_active ? a.mesh_id[id_n - a.id_base] : 0xFFFFFFFFu;
-        float w_n[16];
-        {
-            const uint64_t off = eoff<16>(id_n - a.id_base);  // (an inactive lane re-reads entity 0's row: in bounds)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) w_n[q] = lde(a.world, off, q);
-        }
-        const uint32_t id_nn = i0 + 2 * YH_BLOCK + tid < hi ? a.list[i0 + 2 * YH_BLOCK + tid] : a.id_base;
         for (uint32_t m = tid; m < a.n_meshes; m += YH_BLOCK) wcnt[0][m] = wcnt[1][m] = wcnt[2][m] = wcnt[3][m] = 0;
         lds_barrier();
         const bool active = tid < n_tile;
@@ -1291,27 +1331,48 @@ __global__ __launch_bounds__(YH_BLOCK) void k_bucket_scatter(BucketArgs a) {
             const uint32_t ls = lstart[m] + in_bucket;
             s_pos[ls] = base[m] + in_bucket;
             s_id[ls] = id;
-            s_vc[ls] = a.vcount ? a.vcount[m] : 0u;
+            s_vc[ls] = s_vcount[m];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) rows[ls * 17 + q] = __float_as_uint(w_c[q]);
+            for (int q = 0; q < 16; ++q) rows[ls * 17 + q] = __float_as_uint(w[q]);
         }
         lds_barrier();
         if (tid < a.n_meshes) base[tid] += tile_cnt;
-        if (tid < n_tile) {
-            const uint32_t pos = s_pos[tid];
-            a.out_list[pos] = s_id[tid];
-            a.cmds[pos] = make_uint4(s_vc[tid], 1u, 0u, a.batch_offset + pos);
+        // the next tile's mesh ids and rows (its list entries arrived a tile ago), the list entries of the one after
+        id_c = id_n;
+        id_n = a.list[min(i0 + 2 * YH_BLOCK + tid, last)];
+        m_c = a.mesh_id[id_c - a.id_base];
+        {
+            const uint64_t off = eoff<16>(id_c - a.id_base);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) w[q] = lde(a.world, off, q);
+        }
+        // this tile leaves in bucket order
+        {
+            const uint32_t t = min(tid, n_tile - 1u);
+            const uint32_t pos = s_pos[t];
+            a.out_list[pos] = s_id[t];
+            a.cmds[pos] = make_uint4(s_vc[t], 1u, 0u, a.batch_offset + pos);
         }
         // (streaming stores: the rows are written once and read by another engine; 2.12 -> 1.94 ms at 64M / 16 meshes)
-        for (uint32_t i = tid; i < n_tile * 16u; i += YH_BLOCK)
-            __builtin_nontemporal_store(rows[(i >> 4) * 17 + (i & 15u)], &a.obj[(uint64_t)s_pos[i >> 4] * 16 + (i & 15u)]);
-        lds_barrier();
-        id_c = id_n;
-        id_n = id_nn;
-        m_c = m_n;
+        // thread t writes dword t & 15 of rows t / 16 + 16 j: a wave's store is four whole 64-byte rows
+        {
+            const uint32_t r0 = tid >> 4, c = tid & 15u;
+            uint32_t v[16], p[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) w_c[q] = w_n[q];
-    }
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t r = min(r0 + 16u * j, n_tile - 1u);
+                v[j] = rows[r * 17u + c];
+                p[j] = s_pos[r];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) __builtin_nontemporal_store(v[j], &a.obj[(uint64_t)p[j] * 16 + c]);
+        }
+        lds_barrier();
+    };
+    // The first tile stands outside the loop: nothing has been stored before it, so a wait that leaves "the stores issued
+    // after these loads" outstanding would be wrong there, and one loop for both would have to wait for everything.
+    tile(lo);
+    for (uint64_t i0 = lo + YH_BLOCK; i0 < hi; i0 += YH_BLOCK) tile(i0);  // uniform trip count for the workgroup
 }
 #endif  // YH_K_CONSUMERS
 
