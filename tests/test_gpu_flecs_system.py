@@ -168,8 +168,10 @@ def test_gpu_system_in_real_flecs_equals_the_cpu_systems(oracle, tmp_path, n, le
         assert walks + skipped == fi + 1
         if always_walk:
             assert skipped == 0
-        else:  # the query is iterated on the first frame and on the frames after a structural change, only
+        elif plain or validate:  # the query is iterated on the first frame and on the frames after a structural change, only
             assert walks == rebuilds, f"frame {fi}: {walks} walks for {rebuilds} rebuilds"
+        else:  # incremental mode with trusted observers: later rebuilds take the tables from the observers' lists
+            assert walks == 1, f"frame {fi}: {walks} walks for {rebuilds} rebuilds"
         if plain:
             assert up == down == 2 * g_rows, f"frame {fi}: whole columns travel in plain mode"
         elif not (fi == 0 or structural):
@@ -498,17 +500,21 @@ def test_cameras_follow_their_transforms_in_the_same_frame(oracle, tmp_path, mod
     assert late >= 5, "the script never moved the camera: the test would not tell this frame's frusta from last frame's"
 
 
-@pytest.mark.parametrize("seed,ecs_inputs,stale_from",  # more seeds: YH_STRUCT_SEEDS=40
-                         [(k, k % 4 == 3, 5 if k % 4 == 1 else 0) for k in range(int(os.environ.get("YH_STRUCT_SEEDS", "4")))])
+@pytest.mark.parametrize("seed,ecs_inputs,stale_from,rebuilds_by",  # more seeds: YH_STRUCT_SEEDS=40
+                         [(k, k % 4 == 3, 5 if k % 4 == 1 else 0, "") for k in range(int(os.environ.get("YH_STRUCT_SEEDS", "4")))]
+                         + [(0, False, 0, "lists"), (1, False, 5, "lists"), (3, True, 0, "lists"), (2, False, 0, "walk")])
 def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cpu_systems(oracle, tmp_path, seed, ecs_inputs,
-                                                                                          stale_from):
+                                                                                          stale_from, rebuilds_by):
     """Editor traffic (Editor.zig:590-636, GameApp.zig:204-215): entities created (under old parents, under parents
     created a frame earlier), leaves deleted, leaves and whole subtrees re-parented (same depth and other depths),
     parents with children deleted, mixed with matrix edits, frame after frame.  The system patches what it can (no walk,
     no rebuild) and rebuilds otherwise; either way every row and every visible set equals the CPU systems' - and a
     burst of creations larger than a level's spare slots must fall back to the rebuild.  stale_from: results stay on the
     device from that frame to the last but one (setReadback(0)): the patches then move rows on the device, flecs' columns
-    are compared again after the last frame has brought everything home, the visible sets every frame."""
+    are compared again after the last frame has brought everything home, the visible sets every frame.
+    rebuilds_by: patching off, so that EVERY structural change rebuilds - "lists": from the batches and the observers'
+    lists of touched tables (refresh_batches: the query is walked once, in the first frame), "walk": by walking the query
+    as rounds 1-2 did (YUME_GPU_SYSTEM_NO_REFRESH)."""
     rng = np.random.default_rng(1000 + seed)
     n_frames = int(os.environ.get("YH_STRUCT_FRAMES", "26"))  # a soak: YH_STRUCT_FRAMES=200
     n0, levels, extra = int(os.environ.get("YH_STRUCT_N", "20000")), 6, 6000 * max(1, n_frames // 26)  # a larger world: YH_STRUCT_N=200000
@@ -632,6 +638,11 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
         env["YFH_ECS_INPUTS"] = "1"
     if stale_from:
         env["YFH_READBACK_OFF_FROM"] = str(stale_from)
+    env.pop("YUME_GPU_SYSTEM_NO_REFRESH", None)
+    if rebuilds_by:
+        env["YFH_NO_PATCH"] = "1"
+        if rebuilds_by == "walk":
+            env["YUME_GPU_SYSTEM_NO_REFRESH"] = "1"
     subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
     cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
     gpu = read_out(out_g, n, len(frames), 2 if ecs_inputs else planes.shape[0], oracle.T68, gpu=True)
@@ -667,8 +678,14 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
         exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[here]), np.ascontiguousarray(cull_bounds[here]), cull_planes)
         for f in range(cull_planes.shape[0]):
             assert np.array_equal(np.sort(vis[f]), here[np.flatnonzero(exp_vis[f])]), f"frame {fi} frustum {f}: visible set {stats}"
+    walks = gpu[-1][4][-1][2]
+    if rebuilds_by:
+        assert patches == 0 and rebuilds >= 8, f"every structural frame was meant to rebuild: {patches} patches, {rebuilds} rebuilds"
+        assert (walks == 1) if rebuilds_by == "lists" else (walks == rebuilds), f"{walks} walks of the query for {rebuilds} rebuilds ({rebuilds_by})"
+        return
     assert patches >= 3 and rebuilds >= 1, f"the script was meant to exercise the patch path: {patches} patches, {rebuilds} rebuilds"
     assert not stale_from or stale_patches >= 3, f"patches on device-resident rows were meant to happen: {stale_patches}"
+    assert walks == 1, f"rebuilds after the first frame take the tables from the observers' lists, not from a walk: {walks} walks"
 
 
 @pytest.mark.parametrize("no_patch", [False, True], ids=["patched", "rebuilt"])

@@ -65,6 +65,20 @@ extern "C" int yh_init(int device_id, yh_ctx** out) {
         delete c;
         return YH_ERR_HIP;  // (the message is resolve_static_scratch's)
     }
+    // The process' first host <-> device copy of some size costs the runtime ~8 ms (its copy queues come up then, 1.5 ms
+    // for the same copy afterwards): paid here rather than inside somebody's first frame.  Failure is not an error.
+    {
+        void *d = nullptr, *h = nullptr;
+        const size_t bytes = 1u << 20;
+        if (hipMalloc(&d, bytes) == hipSuccess && hipHostMalloc(&h, bytes, hipHostMallocDefault) == hipSuccess) {
+            memset(h, 0, bytes);
+            (void)hipMemcpy(d, h, bytes, hipMemcpyHostToDevice);
+            (void)hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost);
+        }
+        if (h) (void)hipHostFree(h);
+        if (d) (void)hipFree(d);
+        (void)hipGetLastError();
+    }
     *out = c;
     return YH_OK;
 }

@@ -31,6 +31,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -62,7 +63,11 @@ typedef struct MapEntry {
 
 typedef struct Map {
     MapEntry* e;
-    uint64_t cap; /* power of two */
+    uint64_t cap;   /* power of two */
+    uint64_t pmask; /* entries per partition - 1 */
+    uint32_t pbits; /* 2^pbits partitions (0: one): the top bits of the hash pick the partition, probing wraps inside it */
+    int overflow;   /* a partition was full and a key was dropped (cap >= 2 n and 4096+ entries per partition: never seen) */
+    size_t mapped;  /* bytes, when the table came from mmap (large tables: huge pages where the kernel gives them) */
 } Map;
 
 typedef struct SlotRun {
@@ -95,7 +100,7 @@ struct GpuTransformCullSystem {
     int walk_is_whole_tables;    /* every batch of the last walk was a whole table (offset 0, count = table count) */
     uint64_t walks, walks_skipped;
     uint32_t cached_batches;
-    uint64_t n, cap_n, cached_n;
+    uint64_t n, cap_n, cached_n, cap_cached; /* cap_n / cap_cached: room in walk_entities / cached_entities */
 
     ecs_entity_t* entity_of_slot;
     uint32_t* order; /* batch indices in slot order */
@@ -154,6 +159,7 @@ struct GpuTransformCullSystem {
     uint32_t epoch;
     uint32_t* slot_buf;      /* n entries: slots of a sparse upload / of the changed rows */
     int slot_buf_pinned;
+    uint64_t slot_buf_cap;   /* entries it has room for (>= n_slots) */
     ecs_entity_t observers[8];
     uint64_t last_up_rows, last_down_rows;
     double last_ms[6];       /* the last frame's wall time: tables + inputs, rows up, device frame, rows down and placed; of the first: query walk, slot-order rebuild */
@@ -162,6 +168,7 @@ struct GpuTransformCullSystem {
      * dead on the device (yh_scene_set_alive_range); the observers list the tables rows entered or left; the rows of
      * such a table move to spare slots of its level, its old slots die. */
     int patching;                 /* default on; needs incremental mode and trusted observers */
+    int refresh;                  /* default on: a rebuild takes the tables from the observers' lists, not from a walk (refresh_batches) */
     uint64_t n_slots;             /* slots of the device scene: rows + spare */
     uint32_t level_begin[YH_MAX_LEVELS + 1];
     uint32_t level_fill[YH_MAX_LEVELS]; /* first free slot of every level's range */
@@ -191,43 +198,157 @@ static uint64_t hash64(uint64_t x) {
     return x;
 }
 
+/* Large maps are cut into 16 partitions by the top bits of the hash, each a table of its own (probing wraps inside
+ * the partition): map_fill_mt hands the partitions to helper threads, every one of which then inserts into 1/16 of the
+ * table - a piece that stays in its core's cache - without sharing a line with another thread, so no atomics. */
+#define MAP_PART_BITS 4u
+#define MAP_PART_MIN_CAP 65536u
+#ifdef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE_IF_ANY MADV_POPULATE_WRITE
+#else
+#define MADV_POPULATE_WRITE_IF_ANY 23 /* Linux 5.14+; older kernels refuse it and the pages come on first touch */
+#endif
+static void map_free(Map* m) {
+    if (m->e && m->mapped) munmap(m->e, m->mapped);
+    else free(m->e);
+    m->e = NULL;
+    m->mapped = 0;
+    m->cap = 0;
+}
+/* A fresh table of a million entities is tens of MB of pages nobody has touched: sixteen threads faulting them in 4 KB
+ * at a time contend for the address space's lock (15 + 25 ms of the 1M-entity rebuild were that).  Large tables come
+ * from mmap, transparent huge pages asked for and the pages populated by the kernel in one go. */
+#define MAP_MMAP_MIN_BYTES ((size_t)4 << 20)
 static int map_init(Map* m, uint64_t n) {
     uint64_t cap = 16;
     while (cap < n * 2) cap <<= 1;
-    m->e = (MapEntry*)calloc(cap, sizeof(MapEntry));
+    const size_t bytes = (size_t)cap * sizeof(MapEntry);
+    m->mapped = 0;
+    m->e = NULL;
+    if (bytes >= MAP_MMAP_MIN_BYTES) {
+        void* p = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p != MAP_FAILED) {
+            (void)madvise(p, bytes, MADV_HUGEPAGE);
+            (void)madvise(p, bytes, MADV_POPULATE_WRITE_IF_ANY);
+            m->e = (MapEntry*)p;
+            m->mapped = bytes;
+        }
+    }
+    if (!m->e) m->e = (MapEntry*)calloc(cap, sizeof(MapEntry));
     m->cap = cap;
+    m->pbits = cap >= MAP_PART_MIN_CAP ? MAP_PART_BITS : 0u;
+    m->pmask = (cap >> m->pbits) - 1;
+    m->overflow = 0;
     return m->e ? 0 : -1;
+}
+/* the same table emptied for another fill, when it is large enough for n keys and not absurdly larger */
+static int map_reuse(Map* m, uint64_t n) {
+    if (!m->e || m->cap < n * 2 || m->cap > n * 8 + 64) return 0;
+    memset(m->e, 0, (size_t)m->cap * sizeof(MapEntry));
+    m->overflow = 0;
+    return 1;
+}
+
+/* home slot of a hash */
+static inline MapEntry* map_home(const Map* m, uint64_t h, uint64_t* i) {
+    *i = h & m->pmask;
+    return m->e + (m->pbits ? (h >> (64u - m->pbits)) * (m->pmask + 1) : 0u);
+}
+
+static int map_put_hashed(Map* m, ecs_entity_t k, uint64_t h, uint32_t v) {
+    uint64_t i;
+    MapEntry* part = map_home(m, h, &i);
+    for (uint64_t probes = 0; probes <= m->pmask; ++probes) {
+        MapEntry* e = &part[i];
+        if (!e->key || e->key == k) {
+            const int fresh = e->key == 0;
+            e->key = k;
+            e->value = v;
+            return fresh;
+        }
+        i = (i + 1) & m->pmask;
+    }
+    m->overflow = 1;
+    return 0;
 }
 
 /* returns 1 if the key is new to the map */
-static int map_put(Map* m, ecs_entity_t k, uint32_t v) {
-    uint64_t i = hash64(k) & (m->cap - 1);
-    while (m->e[i].key && m->e[i].key != k) i = (i + 1) & (m->cap - 1);
-    const int fresh = m->e[i].key == 0;
-    m->e[i].key = k;
-    m->e[i].value = v;
-    return fresh;
+static int map_put(Map* m, ecs_entity_t k, uint32_t v) { return map_put_hashed(m, k, hash64(k), v); }
+
+static inline void map_prefetch(const Map* m, ecs_entity_t k, int for_write) {
+    uint64_t i;
+    const MapEntry* part = map_home(m, hash64(k), &i);
+    if (for_write) __builtin_prefetch(&part[i], 1);
+    else __builtin_prefetch(&part[i], 0);
 }
 
 /* keys[i] -> i for every non-zero key.  A map of a million entities is far larger than the caches and every insert a
  * miss: the home slot of the key sixteen ahead is prefetched while this one is placed (43 + 36 ms of the 1M-entity
  * rebuild were these two loops). */
 static void map_fill(Map* m, const ecs_entity_t* keys, uint64_t n) {
-    const uint64_t mask = m->cap - 1;
     for (uint64_t i = 0; i < n; ++i) {
-        if (i + 16 < n) __builtin_prefetch(&m->e[hash64(keys[i + 16]) & mask], 1);
+        if (i + 16 < n) map_prefetch(m, keys[i + 16], 1);
         if (keys[i]) map_put(m, keys[i], (uint32_t)i);
     }
 }
 
+typedef struct MapFillJob {
+    Map* m;
+    const ecs_entity_t* keys;
+    uint64_t n;
+    uint32_t p0, p1; /* partitions [p0, p1) are this thread's */
+} MapFillJob;
+static void* map_fill_parts(void* arg) {
+    const MapFillJob* j = (const MapFillJob*)arg;
+    Map* m = j->m;
+    const uint32_t shift = 64u - m->pbits;
+    for (uint64_t i = 0; i < j->n; ++i) { /* every thread reads all keys (sequential, shared) and places its own */
+        const ecs_entity_t k = j->keys[i];
+        if (!k) continue;
+        const uint64_t h = hash64(k);
+        const uint32_t part = (uint32_t)(h >> shift);
+        if (part >= j->p0 && part < j->p1) map_put_hashed(m, k, h, (uint32_t)i);
+    }
+    return NULL;
+}
+/* the same by up to 16 threads (30 -> ~4 ms per million keys: each thread's share of the table fits its cache) */
+static void map_fill_mt(Map* m, const ecs_entity_t* keys, uint64_t n, int threads) {
+    const uint32_t parts = 1u << m->pbits;
+    uint32_t T = threads < 1 ? 1u : (uint32_t)threads;
+    if (T > parts) T = parts;
+    if (T > MAX_THREADS) T = MAX_THREADS;
+    if (!m->pbits || T < 2 || n < 65536) {
+        map_fill(m, keys, n);
+        return;
+    }
+    pthread_t th[MAX_THREADS];
+    MapFillJob job[MAX_THREADS];
+    int started[MAX_THREADS];
+    for (uint32_t t = 0; t < T; ++t) {
+        job[t].m = m;
+        job[t].keys = keys;
+        job[t].n = n;
+        job[t].p0 = parts * t / T;
+        job[t].p1 = parts * (t + 1) / T;
+        started[t] = t > 0 && pthread_create(&th[t], NULL, map_fill_parts, &job[t]) == 0;
+    }
+    for (uint32_t t = 0; t < T; ++t)
+        if (!started[t]) map_fill_parts(&job[t]);
+    for (uint32_t t = 1; t < T; ++t)
+        if (started[t]) pthread_join(th[t], NULL);
+}
+
 static int map_get(const Map* m, ecs_entity_t k, uint32_t* v) {
-    uint64_t i = hash64(k) & (m->cap - 1);
-    while (m->e[i].key) {
-        if (m->e[i].key == k) {
-            *v = m->e[i].value;
+    uint64_t i;
+    const MapEntry* part = map_home(m, hash64(k), &i);
+    for (uint64_t probes = 0; probes <= m->pmask; ++probes) {
+        const MapEntry* e = &part[i];
+        if (!e->key) return 0;
+        if (e->key == k) {
+            *v = e->value;
             return 1;
         }
-        i = (i + 1) & (m->cap - 1);
+        i = (i + 1) & m->pmask;
     }
     return 0;
 }
@@ -278,6 +399,48 @@ static int reserve_rows(GpuTransformCullSystem* s, uint64_t need) {
     return YH_OK;
 }
 
+/* second half of the walk, shared by the helper threads: column indices and entity ids of the whole tables (read-only
+ * calls into flecs: nothing mutates the world while a system runs) */
+#define COLS_PENDING (-2)
+typedef struct WalkJob {
+    GpuTransformCullSystem* s;
+    uint32_t b0, b1;
+} WalkJob;
+static void* walk_finish_range(void* arg) {
+    const WalkJob* j = (const WalkJob*)arg;
+    GpuTransformCullSystem* s = j->s;
+    for (uint32_t i = j->b0; i < j->b1; ++i) {
+        Batch* b = &s->batches[i];
+        if (b->col_w != COLS_PENDING) continue;
+        b->col_w = ecs_table_get_column_index(s->world, b->table, s->world_id);
+        b->col_l = ecs_table_get_column_index(s->world, b->table, s->local_id);
+        memcpy(s->walk_entities + b->walk_begin, ecs_table_entities(b->table), sizeof(ecs_entity_t) * (size_t)b->count);
+    }
+    return NULL;
+}
+static void walk_finish(GpuTransformCullSystem* s) {
+    uint32_t parts = s->n_batches / 4096u > (uint32_t)s->threads ? (uint32_t)s->threads : s->n_batches / 4096u;
+    if (parts > MAX_THREADS) parts = MAX_THREADS;
+    if (parts < 2) {
+        WalkJob all = {s, 0, s->n_batches};
+        walk_finish_range(&all);
+        return;
+    }
+    pthread_t th[MAX_THREADS];
+    WalkJob job[MAX_THREADS];
+    int started[MAX_THREADS];
+    for (uint32_t p = 0; p < parts; ++p) {
+        job[p].s = s;
+        job[p].b0 = (uint32_t)((uint64_t)s->n_batches * p / parts);
+        job[p].b1 = (uint32_t)((uint64_t)s->n_batches * (p + 1) / parts);
+        started[p] = p > 0 && pthread_create(&th[p], NULL, walk_finish_range, &job[p]) == 0;
+    }
+    for (uint32_t p = 0; p < parts; ++p)
+        if (!started[p]) walk_finish_range(&job[p]);
+    for (uint32_t p = 1; p < parts; ++p)
+        if (started[p]) pthread_join(th[p], NULL);
+}
+
 static int walk(GpuTransformCullSystem* s, ecs_iter_t* it) {
     int rc = YH_OK;
     s->n_batches = 0;
@@ -303,13 +466,19 @@ static int walk(GpuTransformCullSystem* s, ecs_iter_t* it) {
         if ((rc = reserve_rows(s, s->n + (uint64_t)it->count)) != YH_OK) continue;
         Batch* b = &s->batches[s->n_batches++];
         b->table = it->table;
-        b->col_w = it->table ? ecs_table_get_column_index(it->real_world, it->table, s->world_id) : -1;
-        b->col_l = it->table ? ecs_table_get_column_index(it->real_world, it->table, s->local_id) : -1;
-        if (!it->table || it->offset != 0 || it->count != ecs_table_count(it->table) || b->col_w < 0 || b->col_l < 0) {
+        if (!it->table || it->offset != 0 || it->count != ecs_table_count(it->table)) {
             s->walk_is_whole_tables = 0;
+            b->col_w = it->table ? ecs_table_get_column_index(it->real_world, it->table, s->world_id) : -1;
+            b->col_l = it->table ? ecs_table_get_column_index(it->real_world, it->table, s->local_id) : -1;
             b->world_col = ecs_field_w_size(it, ROW, 0);
             b->local_col = ecs_field_w_size(it, ROW, 1);
-        } else { /* a whole table: its columns are fetched when a row of them is first needed (batch_cols) */
+            memcpy(s->walk_entities + s->n, it->entities, sizeof(ecs_entity_t) * (size_t)it->count);
+        } else {
+            /* A whole table (the only kind a reference scene has).  Its two column indices and its entity ids are not
+             * fetched here: that is two map lookups and a copy from one more cold allocation per table, a third of the
+             * walk's time at 300k tables - walk_finish hands both to the helper threads.  The columns themselves are
+             * fetched when a row of them is first needed (batch_cols). */
+            b->col_w = b->col_l = COLS_PENDING;
             b->world_col = b->local_col = NULL;
         }
         b->up_row = NULL;
@@ -318,9 +487,9 @@ static int walk(GpuTransformCullSystem* s, ecs_iter_t* it) {
         b->walk_begin = (uint32_t)s->n;
         b->slot_begin = 0;
         b->level = -1;
-        memcpy(s->walk_entities + s->n, it->entities, sizeof(ecs_entity_t) * (size_t)it->count);
         s->n += (uint64_t)it->count;
     }
+    if (rc == YH_OK) walk_finish(s);
     return rc;
 }
 
@@ -357,6 +526,66 @@ static int by_key(const void* a, const void* b) {
     return x->batch < y->batch ? -1 : (x->batch > y->batch); /* stable: walk order among equals */
 }
 
+/* stable sort by key: three passes of an 11-bit radix sort (keys are slots, < 2^30) instead of qsort's ~18 rounds of
+ * comparator calls per element (300k tables: 15 -> 2 ms); small inputs go through qsort */
+static void sort_keyed(KeyedBatch* a, KeyedBatch* tmp, uint32_t n) {
+    if (n < 1024) {
+        qsort(a, n, sizeof(KeyedBatch), by_key);
+        return;
+    }
+    KeyedBatch *src = a, *dst = tmp;
+    for (uint32_t pass = 0; pass < 3; ++pass) {
+        uint32_t count[2049];
+        const uint32_t shift = 11u * pass;
+        memset(count, 0, sizeof count);
+        for (uint32_t i = 0; i < n; ++i) count[((src[i].key >> shift) & 2047u) + 1]++;
+        for (uint32_t d = 0; d < 2048; ++d) count[d + 1] += count[d];
+        for (uint32_t i = 0; i < n; ++i) dst[count[(src[i].key >> shift) & 2047u]++] = src[i];
+        KeyedBatch* t = src;
+        src = dst;
+        dst = t;
+    }
+    if (src != a) memcpy(a, src, sizeof(KeyedBatch) * n); /* (three passes: the result is in tmp) */
+}
+
+typedef struct RowsToSlotsJob {
+    GpuTransformCullSystem* s;
+    const uint32_t* row_batch;
+    uint64_t i0, i1; /* range of the map's table */
+} RowsToSlotsJob;
+static void* rows_to_slots_range(void* arg) {
+    const RowsToSlotsJob* j = (const RowsToSlotsJob*)arg;
+    const GpuTransformCullSystem* s = j->s;
+    MapEntry* e = s->slot_of.e;
+    for (uint64_t i = j->i0; i < j->i1; ++i) {
+        if (!e[i].key) continue;
+        const uint32_t row = e[i].value;
+        const Batch* b = &s->batches[j->row_batch[row]];
+        e[i].value = b->slot_begin + (row - b->walk_begin);
+    }
+    return NULL;
+}
+static void map_rows_to_slots(GpuTransformCullSystem* s, const uint32_t* row_batch) {
+    const uint64_t cap = s->slot_of.cap;
+    uint32_t parts = cap / 65536u > (uint64_t)s->threads ? (uint32_t)s->threads : (uint32_t)(cap / 65536u);
+    if (parts > MAX_THREADS) parts = MAX_THREADS;
+    if (parts < 1) parts = 1;
+    pthread_t th[MAX_THREADS];
+    RowsToSlotsJob job[MAX_THREADS];
+    int started[MAX_THREADS];
+    for (uint32_t p = 0; p < parts; ++p) {
+        job[p].s = s;
+        job[p].row_batch = row_batch;
+        job[p].i0 = cap * p / parts;
+        job[p].i1 = cap * (p + 1) / parts;
+        started[p] = p > 0 && pthread_create(&th[p], NULL, rows_to_slots_range, &job[p]) == 0;
+    }
+    for (uint32_t p = 0; p < parts; ++p)
+        if (!started[p]) rows_to_slots_range(&job[p]);
+    for (uint32_t p = 1; p < parts; ++p)
+        if (started[p]) pthread_join(th[p], NULL);
+}
+
 static double now_ms(void);
 /* YUME_GPU_SYSTEM_TRACE=1: the rebuild's steps with their wall time on stderr */
 #define TRACE_STEP(what)                                                                  \
@@ -374,41 +603,70 @@ static int rebuild(GpuTransformCullSystem* s) {
     const uint64_t n = s->n;
     const uint32_t nb = s->n_batches;
     int rc = YH_OK;
-    Map batch_of = {0};
+    Map* const rows = &s->slot_of; /* entity -> walk row while the order is worked out, entity -> slot from then on */
     uint32_t* parent_batch = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
     uint32_t* parent_row = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1)); /* walk row of the parent */
     uint32_t* key = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
     /* (slots = rows + the spare slots of every level: at most an eighth more, and SPARE_MIN per level) */
-    uint32_t* parent_index = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n + n / 8 + SPARE_MIN * (YH_MAX_LEVELS + 1)));
     uint32_t* stack = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
-    KeyedBatch* keyed = (KeyedBatch*)malloc(sizeof(KeyedBatch) * (nb ? nb : 1));
+    uint32_t* row_batch = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n ? n : 1)); /* walk row -> batch */
+    uint32_t* by_level = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));        /* batches grouped by level, walk order inside */
+    KeyedBatch* keyed = (KeyedBatch*)malloc(sizeof(KeyedBatch) * (nb ? nb : 1) * 2); /* (second half: the sort's other buffer) */
     uint32_t level_offsets[YH_MAX_LEVELS + 1];
     free(s->order);
     s->order = (uint32_t*)malloc(sizeof(uint32_t) * (nb ? nb : 1));
-    if (!parent_batch || !parent_row || !key || !parent_index || !stack || !keyed || !s->order || map_init(&batch_of, n) != 0) {
+    uint32_t* parent_index = NULL;
+    if (!parent_batch || !parent_row || !key || !stack || !row_batch || !by_level || !keyed || !s->order) {
         rc = YH_ERR_OOM;
         goto done;
     }
-    /* entity -> walk row; the batch of a row is found by binary search over walk_begin */
-    map_fill(&batch_of, s->walk_entities, n);
-    for (uint32_t b = 0; b < nb; ++b) {
-        uint32_t row;
-        if (b + 16 < nb) __builtin_prefetch(&batch_of.e[hash64(s->batches[b + 16].src) & (batch_of.cap - 1)]);
-        if (map_get(&batch_of, s->batches[b].src, &row)) {
-            uint32_t lo = 0, hi = nb - 1;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1) / 2;
-                if (s->batches[mid].walk_begin <= row) lo = mid;
-                else hi = mid - 1;
+    /* entity -> walk row (filled by the helper threads, a partition of the table each), walk row -> batch; then the
+     * parent of every table in two prefetched passes: its row through the map, its batch through the row table */
+    {   /* The list of slots that sparse uploads and changed rows cross PCIe in (page-locked when possible) doubles as the
+         * parent index of this rebuild: yh_upload_hierarchy then copies from page-locked memory (9 -> 1 ms at 1M). */
+        const uint64_t want = n + n / 8 + (uint64_t)SPARE_MIN * (YH_MAX_LEVELS + 1);
+        if (s->slot_buf_cap < want) {
+            if (s->slot_buf_pinned) yh_host_free(s->ctx, s->slot_buf);
+            else free(s->slot_buf);
+            s->slot_buf = (uint32_t*)yh_host_alloc(s->ctx, sizeof(uint32_t) * want);
+            s->slot_buf_pinned = s->slot_buf != NULL;
+            if (!s->slot_buf) s->slot_buf = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)want);
+            s->slot_buf_cap = s->slot_buf ? want : 0;
+            if (!s->slot_buf) {
+                rc = YH_ERR_OOM;
+                goto done;
             }
-            parent_batch[b] = lo;
-            parent_row[b] = row;
-        } else {
-            parent_batch[b] = YH_NO_PARENT; /* the scene root, or any holder of a WorldTransform without a local one */
-            parent_row[b] = YH_NO_PARENT;
+        }
+        parent_index = s->slot_buf;
+    }
+    if (!map_reuse(rows, n + n / 8)) { /* (an eighth of headroom for the entities later patches bring) */
+        map_free(rows);
+        if (map_init(rows, n + n / 8) != 0) {
+            rc = YH_ERR_OOM;
+            goto done;
         }
     }
-    TRACE_STEP("entity map, parents of tables");
+    TRACE_STEP("allocations, the map's table");
+    map_fill_mt(rows, s->walk_entities, n, s->threads);
+    if (rows->overflow) {
+        rc = YH_ERR_OOM;
+        goto done;
+    }
+    TRACE_STEP("entity -> walk row map");
+    for (uint32_t b = 0; b < nb; ++b)
+        for (uint32_t r = 0; r < s->batches[b].count; ++r) row_batch[s->batches[b].walk_begin + r] = b;
+    TRACE_STEP("walk row -> table");
+    for (uint32_t b = 0; b < nb; ++b) {
+        uint32_t row;
+        if (b + 16 < nb) map_prefetch(rows, s->batches[b + 16].src, 0);
+        parent_row[b] = map_get(rows, s->batches[b].src, &row) ? row : YH_NO_PARENT;
+    }
+    for (uint32_t b = 0; b < nb; ++b) {
+        if (b + 16 < nb && parent_row[b + 16] != YH_NO_PARENT) __builtin_prefetch(&row_batch[parent_row[b + 16]]);
+        /* no row: the scene root, or any holder of a WorldTransform without a local one */
+        parent_batch[b] = parent_row[b] != YH_NO_PARENT ? row_batch[parent_row[b]] : YH_NO_PARENT;
+    }
+    TRACE_STEP("parents of tables");
     /* levels, memoised along parent chains (ChildOf is acyclic) */
     uint32_t n_levels = 0;
     for (uint32_t b = 0; b < nb; ++b) {
@@ -434,11 +692,20 @@ static int rebuild(GpuTransformCullSystem* s) {
     if (spare_slots) /* (levels nobody lives on yet: spare slots only) */
         n_levels = n_levels + SPARE_LEVELS <= YH_MAX_LEVELS ? n_levels + SPARE_LEVELS : YH_MAX_LEVELS;
     uint32_t placed = 0, slot = 0;
+    uint32_t level_first[YH_MAX_LEVELS + 2];
+    { /* the batches of every level, walk order inside a level (a counting sort by level) */
+        memset(level_first, 0, sizeof level_first);
+        for (uint32_t b = 0; b < nb; ++b) level_first[(uint32_t)s->batches[b].level + 1]++;
+        for (uint32_t l = 0; l <= YH_MAX_LEVELS; ++l) level_first[l + 1] += level_first[l];
+        uint32_t cursor[YH_MAX_LEVELS + 1];
+        memcpy(cursor, level_first, sizeof cursor);
+        for (uint32_t b = 0; b < nb; ++b) by_level[cursor[(uint32_t)s->batches[b].level]++] = b;
+    }
     for (uint32_t lvl = 0; lvl < n_levels; ++lvl) {
         level_offsets[lvl] = slot;
         const uint32_t first = placed;
-        for (uint32_t b = 0; b < nb; ++b) {
-            if ((uint32_t)s->batches[b].level != lvl) continue;
+        for (uint32_t q = level_first[lvl]; q < level_first[lvl + 1]; ++q) {
+            const uint32_t b = by_level[q];
             if (lvl == 0) {
                 key[b] = 0;
             } else {
@@ -449,7 +716,7 @@ static int rebuild(GpuTransformCullSystem* s) {
             keyed[placed].batch = b;
             placed++;
         }
-        qsort(keyed + first, placed - first, sizeof(KeyedBatch), by_key);
+        sort_keyed(keyed + first, keyed + nb + first, placed - first); /* stable: walk order among equals */
         for (uint32_t i = first; i < placed; ++i) s->order[i] = keyed[i].batch;
         for (uint32_t i = first; i < placed; ++i) {
             Batch* b = &s->batches[s->order[i]];
@@ -518,41 +785,33 @@ static int rebuild(GpuTransformCullSystem* s) {
     s->n_slots = N;
     TRACE_STEP("device scene, staging columns");
     if ((rc = yh_upload_hierarchy(s->scene, parent_index, level_offsets)) != YH_OK) goto done;
+    TRACE_STEP("hierarchy up");
     if (spare_slots) { /* (a scene that is reused may carry the dead slots of earlier patches) */
         if ((rc = yh_scene_set_alive_range(s->scene, 0, N, 1)) != YH_OK) goto done;
         for (uint32_t lvl = 0; lvl < n_levels; ++lvl)
             if ((rc = yh_scene_set_alive_range(s->scene, s->level_fill[lvl], level_offsets[lvl + 1] - s->level_fill[lvl], 0)) != YH_OK)
                 goto done;
     }
+    TRACE_STEP("alive slots");
     memset(s->entity_of_slot, 0, (size_t)N * sizeof(ecs_entity_t)); /* 0: the slot holds no entity */
     memset(s->batch_of, 0xFF, (size_t)N * sizeof(uint32_t));
-    TRACE_STEP("hierarchy up, alive slots");
+    TRACE_STEP("slot tables cleared");
     for (uint32_t b = 0; b < nb; ++b)
         memcpy(s->entity_of_slot + s->batches[b].slot_begin, s->walk_entities + s->batches[b].walk_begin,
                sizeof(ecs_entity_t) * s->batches[b].count);
     s->n_levels = n_levels;
     s->bounds_stale = 1;
     fill_batch_of(s);
-    /* entity -> slot, and the per-slot buffers of the incremental mode */
-    free(s->slot_of.e);
-    s->slot_of.e = NULL;
-    if (map_init(&s->slot_of, N) != 0) {
-        rc = YH_ERR_OOM;
-        goto done;
-    }
-    map_fill(&s->slot_of, s->entity_of_slot, N);
+    TRACE_STEP("entities and tables of slots");
+    /* entity -> slot: the map already holds every entity with its walk row; a row's slot is its batch's first slot + its
+     * offset in the batch.  The values are rewritten in place, a share of the table per helper thread. */
+    map_rows_to_slots(s, row_batch);
     s->slot_entries = n;
     TRACE_STEP("entity -> slot map");
     for (int k = 0; k < 2; ++k) {
         free(s->stamp[k]);
         s->stamp[k] = (uint32_t*)calloc((size_t)(N ? N : 1), sizeof(uint32_t));
     }
-    /* the slots of sparse uploads / changed rows cross PCIe too: page-locked like the staging columns when possible */
-    if (s->slot_buf_pinned) yh_host_free(s->ctx, s->slot_buf);
-    else free(s->slot_buf);
-    s->slot_buf = (uint32_t*)yh_host_alloc(s->ctx, sizeof(uint32_t) * (uint64_t)(N ? N : 1));
-    s->slot_buf_pinned = s->slot_buf != NULL;
-    if (!s->slot_buf) s->slot_buf = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(N ? N : 1));
     s->epoch = 0;
     if (!s->stamp[0] || !s->stamp[1] || !s->slot_buf) {
         rc = YH_ERR_OOM;
@@ -563,7 +822,15 @@ static int rebuild(GpuTransformCullSystem* s) {
 
     /* remember this walk */
     {
-        ecs_entity_t* ce = (ecs_entity_t*)realloc(s->cached_entities, (size_t)(n ? n : 1) * sizeof(ecs_entity_t));
+        /* (the walk's entity ids become the remembered ones by a swap of the two buffers: 8 MB not copied) */
+        ecs_entity_t* ce = s->walk_entities;
+        s->walk_entities = s->cached_entities;
+        s->cached_entities = ce;
+        {
+            const uint64_t c = s->cap_n;
+            s->cap_n = s->cap_cached;
+            s->cap_cached = c;
+        }
         ecs_entity_t* cs = (ecs_entity_t*)realloc(s->cached_src, (size_t)(nb ? nb : 1) * sizeof(ecs_entity_t));
         uint32_t* cc = (uint32_t*)realloc(s->cached_counts, (size_t)(nb ? nb : 1) * sizeof(uint32_t));
         int32_t* cl = (int32_t*)realloc(s->cached_levels, (size_t)(nb ? nb : 1) * sizeof(int32_t));
@@ -574,7 +841,6 @@ static int rebuild(GpuTransformCullSystem* s) {
         if (ct) s->cached_tables = ct;
         if (ccol) s->cached_cols = ccol;
         if (cl) s->cached_levels = cl;
-        if (ce) s->cached_entities = ce;
         if (cs) s->cached_src = cs;
         if (cc) s->cached_counts = cc;
         if (!ce || !cs || !cc || !cl || !ct || !ccol || !cslot) {
@@ -583,7 +849,6 @@ static int rebuild(GpuTransformCullSystem* s) {
             rc = YH_ERR_OOM;
             goto done;
         }
-        memcpy(ce, s->walk_entities, (size_t)n * sizeof(ecs_entity_t));
         for (uint32_t b = 0; b < nb; ++b) {
             cs[b] = s->batches[b].src;
             cc[b] = s->batches[b].count;
@@ -601,14 +866,17 @@ static int rebuild(GpuTransformCullSystem* s) {
     s->rebuilds += 1;
     TRACE_STEP("walk remembered");
 done:
-    free(batch_of.e);
     free(parent_batch);
     free(parent_row);
     free(key);
-    free(parent_index);
     free(stack);
+    free(row_batch);
+    free(by_level);
     free(keyed);
-    if (rc != YH_OK) s->cached_n = 0, s->cached_batches = 0;
+    if (rc != YH_OK) {
+        s->cached_n = 0, s->cached_batches = 0;
+        map_free(&s->slot_of); /* (it may hold walk rows, not slots) */
+    }
     return rc;
 }
 
@@ -618,8 +886,7 @@ static int mesh_table_reset(GpuTransformCullSystem* s) {
     if (!s->mesh_vcount) s->mesh_vcount = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)MESH_TABLE_MAX);
     if (!s->entry_material) s->entry_material = (const void**)malloc(sizeof(void*) * (size_t)MESH_TABLE_MAX);
     if (!s->entry_mesh) s->entry_mesh = (const void**)malloc(sizeof(void*) * (size_t)MESH_TABLE_MAX);
-    free(s->mesh_index.e);
-    s->mesh_index.e = NULL;
+    map_free(&s->mesh_index);
     if (!s->mesh_table || !s->mesh_vcount || !s->entry_material || !s->entry_mesh || map_init(&s->mesh_index, 4096) != 0) return YH_ERR_OOM;
     memset(s->mesh_table, 0, sizeof(float) * 6); /* entry 0: no mesh = an empty box at the origin */
     s->mesh_vcount[0] = 0;
@@ -658,7 +925,7 @@ static int mesh_table_entry(GpuTransformCullSystem* s, const uint8_t* mesh, cons
         if (map_init(&bigger, s->mesh_index.cap) != 0) return YH_ERR_OOM; /* (map_init doubles what it is asked for) */
         for (uint64_t q = 0; q < s->mesh_index.cap; ++q)
             if (s->mesh_index.e[q].key) map_put(&bigger, s->mesh_index.e[q].key, s->mesh_index.e[q].value);
-        free(s->mesh_index.e);
+        map_free(&s->mesh_index);
         s->mesh_index = bigger;
     }
     float mm[6];
@@ -1108,7 +1375,6 @@ static void* gather_range(void* arg) {
     GatherJob* g = (GatherJob*)arg;
     GpuTransformCullSystem* s = g->s;
     const int k = g->k;
-    const uint64_t mask = s->slot_of.cap - 1;
     const ecs_entity_t* ents = s->dirty[k];
     uint32_t* stamp = s->stamp[k];
     uint8_t* stage = g->stage + g->i0 * ROW;
@@ -1118,7 +1384,7 @@ static void* gather_range(void* arg) {
     const uint8_t* src[GATHER_BLOCK];
     for (uint64_t i0 = g->i0; i0 < g->i1; i0 += GATHER_BLOCK) {
         const uint32_t nb = (uint32_t)(g->i1 - i0 < GATHER_BLOCK ? g->i1 - i0 : GATHER_BLOCK);
-        for (uint32_t j = 0; j < nb; ++j) __builtin_prefetch(&s->slot_of.e[hash64(ents[i0 + j]) & mask]);
+        for (uint32_t j = 0; j < nb; ++j) map_prefetch(&s->slot_of, ents[i0 + j], 0);
         for (uint32_t j = 0; j < nb; ++j) {
             if (!slot_lookup(s, ents[i0 + j], &slot[j])) {
                 slot[j] = UINT32_MAX; /* not a row of this system (the root, or an entity deleted since) */
@@ -1741,7 +2007,7 @@ done:
     free(kids);
     free(reloc);
     free(new_level);
-    free(moved.e);
+    map_free(&moved);
     free(mv_src);
     free(mv_dst);
     free(fresh_slots);
@@ -1755,7 +2021,7 @@ not_a_patch:
     free(kids);
     free(reloc);
     free(new_level);
-    free(moved.e);
+    map_free(&moved);
     free(mv_src);
     free(mv_dst);
     free(fresh_slots);
@@ -1763,6 +2029,176 @@ not_a_patch:
     free(fresh_l);
     for (uint32_t l = 0; l < YH_MAX_LEVELS; ++l) free(plan[l]);
     return 1;
+}
+
+/* A rebuild without a walk of the query.  When the structure changed in a way patch() does not follow (a level's spare
+ * slots used up, too many rows moving, patching switched off) the batches still describe every table as of the last
+ * frame and the observers have listed every table that rows entered or left since - so the new batch list is the old
+ * one minus the batches of deleted or emptied tables, with the listed tables read afresh and the new ones appended;
+ * flecs' own iteration of 300k cached tables (~100 ms per million entities) is not needed to find that out.  rebuild()
+ * then sorts them into slots as after a walk (tables of one level that share a parent slot keep the order of this
+ * list instead of the query's: the order of siblings' tables is not defined by the reference either).
+ * Returns YH_OK (batches, walk_entities, n describe the world: rebuild), or 1: walk the query instead - a listed table
+ * holds a WorldTransform without a LocalTransform (a holder of a parent matrix came or went: the Up term may resolve differently),
+ * a new table's parent has no WorldTransform, a kept table's parent left. */
+static int refresh_batches(GpuTransformCullSystem* s) {
+    if (!s->walk_is_whole_tables || !s->entity_of_slot || !s->n_batches) return 1;
+    uint32_t nt = 0, nd = 0;
+    if (s->n_touched) {
+        qsort(s->touched, s->n_touched, sizeof(ecs_table_t*), by_ptr);
+        for (uint32_t i = 0; i < s->n_touched; ++i)
+            if (!nt || s->touched[nt - 1] != s->touched[i]) s->touched[nt++] = s->touched[i];
+    }
+    if (s->n_deleted) {
+        qsort(s->deleted, s->n_deleted, sizeof(ecs_table_t*), by_ptr);
+        for (uint32_t i = 0; i < s->n_deleted; ++i)
+            if (!nd || s->deleted[nd - 1] != s->deleted[i]) s->deleted[nd++] = s->deleted[i];
+    }
+    int rc = 1;
+    const uint32_t nb_old = s->n_batches;
+    uint8_t* seen = (uint8_t*)calloc((size_t)nt + 1, 1);       /* listed table i had a batch */
+    Batch* fresh = (Batch*)malloc(sizeof(Batch) * ((size_t)nb_old + nt + 1));
+    Map left = {0}; /* entities of batches that die or are read afresh -> 0, those found again in a listed table -> 1 */
+    uint64_t rows_old = 0;
+    uint32_t nf = 0;
+    uint64_t n = 0;
+    if (!seen || !fresh) {
+        rc = YH_ERR_OOM;
+        goto done;
+    }
+    /* A listed table with a WorldTransform but no LocalTransform holds (or held) entities that are parents only - the
+     * scene root's kind: one of them came or went, so the Up term of tables that are not listed may resolve differently
+     * now.  (A table with the LocalTransform alone is what an entity passes through while it is being created: never
+     * matched, never a source.) */
+    for (uint32_t i = 0; i < nt; ++i) {
+        const int w = ecs_table_get_column_index(s->world, s->touched[i], s->world_id) >= 0;
+        const int l = ecs_table_get_column_index(s->world, s->touched[i], s->local_id) >= 0;
+        if (w && !l) goto done; /* rc = 1 */
+    }
+    /* old batches: dead ones and those of deleted tables go, those of listed tables are read afresh below */
+    for (uint32_t b = 0; b < nb_old; ++b) {
+        const Batch* bt = &s->batches[b];
+        if (!bt->count || !bt->table) continue;
+        uint32_t lo = 0, hi = nd;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) / 2;
+            if ((uintptr_t)s->deleted[mid] < (uintptr_t)bt->table) lo = mid + 1;
+            else hi = mid;
+        }
+        const int deleted = lo < nd && s->deleted[lo] == bt->table;
+        lo = 0, hi = nt;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) / 2;
+            if ((uintptr_t)s->touched[mid] < (uintptr_t)bt->table) lo = mid + 1;
+            else hi = mid;
+        }
+        const int listed = !deleted && lo < nt && s->touched[lo] == bt->table;
+        if (deleted || listed) {
+            rows_old += bt->count;
+            if (listed) seen[lo] = 1;
+            fresh[nf] = *bt; /* (kept for the moment, marked: its old rows are needed for the map below) */
+            fresh[nf].level = deleted ? -2 : -3;
+            fresh[nf].walk_begin = lo; /* index into touched[] */
+            nf++;
+            continue;
+        }
+        fresh[nf] = *bt;
+        fresh[nf].level = -1;
+        nf++;
+    }
+    {
+        uint64_t rows_new = 0;
+        for (uint32_t i = 0; i < nt; ++i) rows_new += (uint64_t)ecs_table_count(s->touched[i]);
+        if (map_init(&left, rows_old + rows_new + 8) != 0) {
+            rc = YH_ERR_OOM;
+            goto done;
+        }
+    }
+    for (uint32_t b = 0; b < nf; ++b)
+        if (fresh[b].level <= -2)
+            for (uint32_t r = 0; r < fresh[b].count; ++r) map_put(&left, s->entity_of_slot[fresh[b].slot_begin + r], 0);
+    /* the listed tables as they are now */
+    uint32_t kept = 0;
+    for (uint32_t b = 0; b < nf; ++b) { /* compact: batches of deleted tables drop out, listed ones are re-read in place */
+        Batch bt = fresh[b];
+        if (bt.level == -2) continue;
+        if (bt.level == -3) {
+            ecs_table_t* t = s->touched[bt.walk_begin];
+            bt.col_w = ecs_table_get_column_index(s->world, t, s->world_id);
+            bt.col_l = ecs_table_get_column_index(s->world, t, s->local_id);
+            bt.count = bt.col_w >= 0 && bt.col_l >= 0 ? (uint32_t)ecs_table_count(t) : 0u;
+            if (bt.count && (ecs_table_has_id(s->world, t, EcsDisabled) || ecs_table_has_id(s->world, t, EcsPrefab))) bt.count = 0;
+            if (!bt.count) continue;
+            bt.level = -3; /* (entities from the table, not from the slots) */
+        }
+        fresh[kept++] = bt;
+    }
+    nf = kept;
+    for (uint32_t i = 0; i < nt; ++i) { /* tables this system has not held */
+        if (seen[i]) continue;
+        ecs_table_t* t = s->touched[i];
+        Batch bt;
+        memset(&bt, 0, sizeof bt);
+        bt.table = t;
+        bt.col_w = ecs_table_get_column_index(s->world, t, s->world_id);
+        bt.col_l = ecs_table_get_column_index(s->world, t, s->local_id);
+        bt.count = bt.col_w >= 0 && bt.col_l >= 0 ? (uint32_t)ecs_table_count(t) : 0u;
+        if (bt.count && (ecs_table_has_id(s->world, t, EcsDisabled) || ecs_table_has_id(s->world, t, EcsPrefab))) bt.count = 0;
+        if (!bt.count) continue;
+        bt.src = ecs_get_parent(s->world, ecs_table_entities(t)[0]); /* ChildOf is part of the archetype: one parent per table */
+        if (!bt.src) continue;                                        /* no parent: the Up term does not match this table */
+        if (!ecs_has_id(s->world, bt.src, s->world_id)) goto done;    /* Up resolves further up, or not at all: rc = 1 */
+        bt.level = -3;
+        fresh[nf++] = bt;
+    }
+    for (uint32_t b = 0; b < nf; ++b)
+        if (fresh[b].level == -3) {
+            const ecs_entity_t* ents = ecs_table_entities(fresh[b].table);
+            for (uint32_t r = 0; r < fresh[b].count; ++r) map_put(&left, ents[r], 1);
+        }
+    /* a table that stays while its parent row left is not something this list can describe: the query decides */
+    for (uint32_t b = 0; b < nf; ++b) {
+        uint32_t there;
+        if (fresh[b].src != s->root && map_get(&left, fresh[b].src, &there) && !there) goto done; /* rc = 1 */
+        n += fresh[b].count;
+    }
+    if (n > 0x40000000ull || !nf) goto done;
+    if (reserve_rows(s, n) != YH_OK) {
+        rc = YH_ERR_OOM;
+        goto done;
+    }
+    {   /* walk order = this list's order; entities of untouched batches from their slots */
+        uint64_t row = 0;
+        for (uint32_t b = 0; b < nf; ++b) {
+            Batch* bt = &fresh[b];
+            /* (walk_entities is not entity_of_slot: no overlap) */
+            if (bt->level == -3) memcpy(s->walk_entities + row, ecs_table_entities(bt->table), sizeof(ecs_entity_t) * bt->count);
+            else memcpy(s->walk_entities + row, s->entity_of_slot + bt->slot_begin, sizeof(ecs_entity_t) * bt->count);
+            row += bt->count;
+        }
+        row = 0;
+        for (uint32_t b = 0; b < nf; ++b) {
+            Batch* bt = &fresh[b];
+            bt->world_col = bt->local_col = NULL; /* fetched on first use (batch_cols) */
+            bt->up_row = NULL;
+            bt->walk_begin = (uint32_t)row;
+            bt->slot_begin = 0;
+            bt->level = -1;
+            row += bt->count;
+        }
+    }
+    free(s->batches);
+    s->batches = fresh;
+    s->cap_batches = nb_old + nt + 1;
+    s->n_batches = nf;
+    s->n = n;
+    fresh = NULL;
+    rc = YH_OK;
+done:
+    free(seen);
+    free(fresh);
+    map_free(&left);
+    return rc;
 }
 
 static double now_ms(void) {
@@ -1869,13 +2305,27 @@ static void run(ecs_iter_t* it) {
         s->walks_skipped += 1;
         s->frames_clean += 1;
     } else {
+        /* the batches were the world's tables a frame ago and the observers' lists of what changed since are complete */
+        const int lists_complete = s->batches_live && !s->need_full && s->skip_walks && s->trust_observers && s->incremental &&
+                                   s->scene && it->query && s->refresh && (s->n_touched || s->n_deleted);
         s->batches_live = 0;
         s->structure_dirty = 0; /* (cleared first: what the walk below sees is what the flag stands for) */
-        s->n_touched = s->n_deleted = 0;
         s->need_full = 0;
         if (s->skip_walks && restore_walk(s, it)) {
             ecs_iter_fini(it);
+            s->n_touched = s->n_deleted = 0;
+        } else if (lists_complete && (rc = refresh_batches(s)) == YH_OK) {
+            ecs_iter_fini(it); /* the batches were brought up to date from the observers' lists: no walk */
+            s->walks_skipped += 1;
+            s->n_touched = s->n_deleted = 0;
+            rebuilt = 1;
+            s->cached_match_count = ecs_query_match_count(it->query);
+        } else if (rc < 0) {
+            ecs_iter_fini(it);
+            s->status = rc;
+            return;
         } else {
+            s->n_touched = s->n_deleted = 0;
             rc = walk(s, it);
             s->last_ms[4] = now_ms() - t_begin;
             if (rc != YH_OK || s->n == 0) {
@@ -2080,6 +2530,7 @@ ecs_entity_t GpuTransformCullSystem_registerTo(ecs_world_t* world, ecs_entity_t 
     s->structure_dirty = 1;
     s->readback = 1;
     s->patching = 1;
+    s->refresh = getenv("YUME_GPU_SYSTEM_NO_REFRESH") == NULL; /* (the knob: A/B and the tests that compare both ways) */
     {
         long cpus = sysconf(_SC_NPROCESSORS_ONLN);
         s->threads = cpus >= 16 ? 16 : (cpus > 1 ? (int)cpus : 1); /* placing rows is bound by memory latency: helpers overlap the misses */
@@ -2419,7 +2870,7 @@ void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     free_stage(s);
     free(s->batch_of);
     free(s->bounds);
-    free(s->slot_of.e);
+    map_free(&s->slot_of);
     for (int k = 0; k < 2; ++k) {
         free(s->dirty[k]);
         free(s->stamp[k]);
@@ -2435,7 +2886,7 @@ void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     free(s->mesh_vcount);
     free((void*)s->entry_material);
     free((void*)s->entry_mesh);
-    free(s->mesh_index.e);
+    map_free(&s->mesh_index);
     free(s->cached_slot);
     free(s);
 }
