@@ -987,32 +987,91 @@ static int mesh_table_upload(GpuTransformCullSystem* s) {
 /* Bounds from the Mesh component (engine/components/mesh.zig: `Mesh{ ref: *meshes.Mesh }`; the AABB is
  * meshes.Mesh.bounds, engine/meshes.zig:72-95, 104-110): one table entry per distinct mesh, entry 0 the empty box of
  * entities that have none, a u32 id per entity.  setBounds overrides get entries of their own. */
+typedef struct MeshRefsJob {
+    GpuTransformCullSystem* s;
+    const uint8_t** refs; /* per slot: the Mesh component's pointer (NULL: no mesh) */
+    const void** mats;    /* per slot: the Material component's pointer, or NULL (array absent without a Material id) */
+    uint32_t b0, b1;
+} MeshRefsJob;
+/* the Mesh / Material columns of a range of batches into per-slot arrays: two column lookups per table and one cold
+ * column each, shared by the helper threads (read-only calls into flecs) */
+static void* mesh_refs_range(void* arg) {
+    const MeshRefsJob* j = (const MeshRefsJob*)arg;
+    GpuTransformCullSystem* s = j->s;
+    for (uint32_t bi = j->b0; bi < j->b1; ++bi) {
+        const Batch* b = &s->batches[bi];
+        if (!b->table || !b->count) continue;
+        const int32_t col = ecs_table_get_column_index(s->world, b->table, s->mesh_id);
+        if (col < 0) continue;
+        memcpy(j->refs + b->slot_begin, ecs_table_get_column(b->table, col, 0), sizeof(void*) * b->count);
+        const int32_t mcol = j->mats ? ecs_table_get_column_index(s->world, b->table, s->material_id) : -1;
+        if (mcol >= 0) memcpy(j->mats + b->slot_begin, ecs_table_get_column(b->table, mcol, 0), sizeof(void*) * b->count);
+    }
+    return NULL;
+}
+
 static int upload_bounds_from_meshes(GpuTransformCullSystem* s) {
     const uint64_t n = s->n_slots;
     int rc = mesh_table_reset(s);
     uint32_t* ids = (uint32_t*)calloc((size_t)(n ? n : 1), sizeof(uint32_t));
-    if (!ids) rc = YH_ERR_OOM;
-    for (uint32_t bi = 0; bi < s->n_batches && rc == YH_OK; ++bi) {
-        const Batch* b = &s->batches[bi];
-        if (b->table && b->count) rc = mesh_ids_of_batch(s, b, ids + b->slot_begin);
+    const uint8_t** refs = (const uint8_t**)calloc((size_t)(n ? n : 1), sizeof(void*));
+    const void** mats = s->material_id ? (const void**)calloc((size_t)(n ? n : 1), sizeof(void*)) : NULL;
+    if (!ids || !refs || (s->material_id && !mats)) rc = YH_ERR_OOM;
+    if (rc != YH_OK) goto done;
+    {   /* (1) the components' pointers, per slot, by the helper threads */
+        uint32_t parts = s->n_batches / 4096u > (uint32_t)s->threads ? (uint32_t)s->threads : s->n_batches / 4096u;
+        if (parts > MAX_THREADS) parts = MAX_THREADS;
+        if (parts < 1) parts = 1;
+        pthread_t th[MAX_THREADS];
+        MeshRefsJob job[MAX_THREADS];
+        int started[MAX_THREADS];
+        for (uint32_t p = 0; p < parts; ++p) {
+            job[p].s = s;
+            job[p].refs = refs;
+            job[p].mats = mats;
+            job[p].b0 = (uint32_t)((uint64_t)s->n_batches * p / parts);
+            job[p].b1 = (uint32_t)((uint64_t)s->n_batches * (p + 1) / parts);
+            started[p] = p > 0 && pthread_create(&th[p], NULL, mesh_refs_range, &job[p]) == 0;
+        }
+        for (uint32_t p = 0; p < parts; ++p)
+            if (!started[p]) mesh_refs_range(&job[p]);
+        for (uint32_t p = 1; p < parts; ++p)
+            if (started[p]) pthread_join(th[p], NULL);
+    }
+    {   /* (2) table entries: one hash lookup per run of slots that share a mesh and a material (this thread: the table grows) */
+        const uint8_t* prev = NULL;
+        const void* prev_mat = NULL;
+        uint32_t prev_id = 0;
+        for (uint64_t e = 0; e < n && rc == YH_OK; ++e) {
+            const uint8_t* mesh = refs[e];
+            const void* mat = mats ? mats[e] : NULL;
+            if (!mesh) continue;
+            if (mesh != prev || mat != prev_mat) {
+                rc = mesh_table_entry(s, mesh, mat, &prev_id);
+                prev = mesh;
+                prev_mat = mat;
+            }
+            ids[e] = prev_id;
+        }
+        for (uint64_t e = 0; e < n && rc == YH_OK && s->bounds_n; ++e) { /* per-entity overrides: entries of their own */
+            const BoundsEntry* o = s->entity_of_slot[e] ? bounds_find(s, s->entity_of_slot[e]) : NULL;
+            if (o) rc = mesh_table_append(s, o->mm, 0, &ids[e]);
+        }
     }
     if (rc != YH_OK) goto done;
     /* ids first while they are all 0 .. old table, then the table, then the ids (the table may not shrink below an
      * id in use): zero ids are valid for every table */
-    {
-        uint32_t* zero = (uint32_t*)calloc((size_t)(n ? n : 1), sizeof(uint32_t));
-        if (!zero) {
-            rc = YH_ERR_OOM;
-            goto done;
-        }
-        rc = s->n_meshes ? yh_upload_mesh_ids(s->scene, zero, 0, n) : YH_OK;
-        free(zero);
+    if (s->n_meshes) {
+        memset(refs, 0, (size_t)n * sizeof(uint32_t)); /* (done with: n zero ids) */
+        rc = yh_upload_mesh_ids(s->scene, (const uint32_t*)refs, 0, n);
     }
     if (rc == YH_OK) rc = mesh_table_upload(s);
     if (rc == YH_OK) rc = yh_upload_mesh_ids(s->scene, ids, 0, n);
     if (rc == YH_OK) s->bounds_stale = 0;
 done:
     free(ids);
+    free(refs);
+    free(mats);
     return rc;
 }
 
