@@ -23,6 +23,21 @@ __global__ __launch_bounds__(256) void k_scatter_probe(uint32_t* __restrict__ ou
     }
 }
 
+// the plain streaming ceilings for comparison: every lane one dword, or one 16-byte piece, consecutive addresses
+__global__ __launch_bounds__(256) void k_fill1(uint32_t* __restrict__ out, uint64_t n, int nt) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        if (nt) __builtin_nontemporal_store((uint32_t)i, out + i);
+        else out[i] = (uint32_t)i;
+    }
+}
+__global__ __launch_bounds__(256) void k_fill4(uint4* __restrict__ out, uint64_t n, int nt) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint4 v = make_uint4((uint32_t)i, 1u, 2u, 3u);
+        if (nt) __builtin_nontemporal_store(v.x, &out[i].x), __builtin_nontemporal_store(v.y, &out[i].y), __builtin_nontemporal_store(v.z, &out[i].z), __builtin_nontemporal_store(v.w, &out[i].w);
+        else out[i] = v;
+    }
+}
+
 int main(int argc, char** argv) {
     const uint64_t total_rows = argc > 1 ? strtoull(argv[1], 0, 10) : 41943040ull;  // 2.68 GB of rows
     uint32_t* out;
@@ -30,6 +45,25 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
+    for (int width = 1; width <= 4; width += 3)
+        for (int nt = 0; nt <= (width == 1 ? 1 : 0); ++nt)
+            for (uint32_t grid : {2048u, 16384u, 163840u}) {
+                const uint64_t n = total_rows * 16 / width;
+                float best = 1e9f;
+                for (int rep = 0; rep < 4; ++rep) {
+                    CK(hipEventRecord(e0));
+                    if (width == 1) hipLaunchKernelGGL(k_fill1, dim3(grid), dim3(256), 0, 0, out, n, nt);
+                    else hipLaunchKernelGGL(k_fill4, dim3(grid), dim3(256), 0, 0, (uint4*)out, n, nt);
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (rep && ms < best) best = ms;
+                }
+                printf("plain fill, %d-byte stores%s, %6u workgroups: %.3f ms, %.2f TB/s\n", 4 * width, nt ? " (nt)" : "", grid, best,
+                       (double)total_rows * 64 / best * 1e-9);
+                fflush(stdout);
+            }
     const uint32_t Es[] = {256, 512, 1024, 2048, 4096, 16384};
     const uint32_t slices[] = {2048, 8192, 32768};
     for (int nt = 1; nt >= 0; --nt)
