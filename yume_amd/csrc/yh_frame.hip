@@ -145,13 +145,19 @@ static std::string launch_chain_mat4(int G, bool has_base, dim3 grid, hipStream_
     return launch_chain_mat4_g<BOUNDS, false>(G, grid, st, a, root_dirty);
 }
 
+template <int BOUNDS, bool SPEC>
+static std::string launch_mat4_s(bool has_base, bool big, dim3 grid, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
+    if (has_base && big) hipLaunchKernelGGL((k_level_mat4<BOUNDS, true, true, SPEC>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
+    else if (has_base) hipLaunchKernelGGL((k_level_mat4<BOUNDS, true, false, SPEC>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
+    else if (big) hipLaunchKernelGGL((k_level_mat4<BOUNDS, false, true, SPEC>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
+    else hipLaunchKernelGGL((k_level_mat4<BOUNDS, false, false, SPEC>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
+    return kname("void k_level_mat4<%d, %s, %s, %s>(FrameArgs, unsigned int)", BOUNDS, tf(has_base), tf(big), tf(SPEC));
+}
+// spec: most rows are expected to be clean (k_level_mat4's SPEC)
 template <int BOUNDS>
-static std::string launch_mat4(bool has_base, bool big, dim3 grid, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
-    if (has_base && big) hipLaunchKernelGGL((k_level_mat4<BOUNDS, true, true>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
-    else if (has_base) hipLaunchKernelGGL((k_level_mat4<BOUNDS, true, false>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
-    else if (big) hipLaunchKernelGGL((k_level_mat4<BOUNDS, false, true>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
-    else hipLaunchKernelGGL((k_level_mat4<BOUNDS, false, false>), grid, dim3(YH_BLOCK), 0, st, a, root_dirty);
-    return kname("void k_level_mat4<%d, %s, %s>(FrameArgs, unsigned int)", BOUNDS, tf(has_base), tf(big));
+static std::string launch_mat4(bool has_base, bool big, bool spec, dim3 grid, hipStream_t st, const FrameArgs& a, uint32_t root_dirty) {
+    if (spec) return launch_mat4_s<BOUNDS, true>(has_base, big, grid, st, a, root_dirty);
+    return launch_mat4_s<BOUNDS, false>(has_base, big, grid, st, a, root_dirty);
 }
 
 static int ensure_kev(yh_scene* s) {
@@ -440,9 +446,11 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
                 else kn = launch_chain_mat4<2>(G, has_base, grid, st, a, s->root_dirty);
             } else {
                 const bool big = s->n >= s->big_tree;  // 12.5M columns, all dirty: 452 -> 417 us with streamed locals and bounds
-                if (bounds == 0) kn = launch_mat4<0>(has_base, big, grid, st, a, s->root_dirty);
-                else if (bounds == 1) kn = launch_mat4<1>(has_base, big, grid, st, a, s->root_dirty);
-                else kn = launch_mat4<2>(has_base, big, grid, st, a, s->root_dirty);
+                // a frame that is not flagged all-dirty and whose root did not move is expected to find most rows clean
+                const bool spec = s->spec_clean && !(flags & YH_FRAME_ALL_DIRTY) && !s->root_dirty;
+                if (bounds == 0) kn = launch_mat4<0>(has_base, big, spec, grid, st, a, s->root_dirty);
+                else if (bounds == 1) kn = launch_mat4<1>(has_base, big, spec, grid, st, a, s->root_dirty);
+                else kn = launch_mat4<2>(has_base, big, spec, grid, st, a, s->root_dirty);
             }
             HIP_TRY(ctx, hipGetLastError());
             s->group_kernel[gi] = kn;

@@ -610,7 +610,13 @@ __global__ __launch_bounds__(YH_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) v
 // TransformSyncSystem.zig:60-73, one level per launch (the parent's dirty flag must already be this
 // frame's), followed by the culling stage.  The dirty reset of PostTransformSystem.zig:31-35 is done by
 // k_clear_dirty after the last level.
-template <int BOUNDS, bool HAS_BASE, bool BIG>  // BIG: the scene outgrows the Infinity Cache, read-once rows are streamed
+// SPEC (frames in which most rows are expected to be clean - every frame that is not flagged all-dirty and whose root
+// did not move): a clean row needs its stored world matrix for the cull, and which branch a row takes is known only
+// after parent index -> parent flag, two dependent loads.  SPEC issues the row's own loads - flags, bounds, the stored
+// world matrix - before that chain instead of after it: three memory round trips become two, and a dirty row has
+// fetched 64 bytes it does not use (the reverse branch uses them).  The bounds, needed by every row, come first in
+// both variants.
+template <int BOUNDS, bool HAS_BASE, bool BIG, bool SPEC>  // BIG: the scene outgrows the Infinity Cache, read-once rows are streamed
 __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, const uint32_t root_dirty) {
     const uint32_t tid = threadIdx.x;
     const uint32_t tile = xcd_tile(a, blockIdx.x);
@@ -622,16 +628,16 @@ __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, cons
     uint32_t vmask = 0, bmask = 0;
     if (valid) {
         uint32_t bp = 0;
-        bool pd;
-        if (HAS_BASE) {
-            bp = a.parent[e];
-            pd = a.wdirty[bp] != 0;
-        } else {
-            pd = root_dirty != 0;
-        }
-        const bool ld = a.ldirty[e] != 0;
-        const bool wd = a.wdirty[e] != 0;
+        if (HAS_BASE) bp = a.parent[e];
+        const uint8_t ld8 = a.ldirty[e], wd8 = a.wdirty[e];
+        float b[6] = {0, 0, 0, 0, 0, 0};
+        uint32_t mesh = 0;
+        if (BOUNDS == 1) load_row<6, BIG>(a.bounds, e, b);
+        else if (BOUNDS == 2) mesh = a.mesh_id[e];
         M4 w;
+        if (SPEC) load_row<16>(a.world, e, w.v);
+        const bool pd = HAS_BASE ? a.wdirty[bp] != 0 : root_dirty != 0;
+        const bool ld = ld8 != 0, wd = wd8 != 0;
         if (pd || ld || wd) {  // :62-64
             M4 pm;
             if (HAS_BASE) {
@@ -647,22 +653,16 @@ __global__ __launch_bounds__(YH_BLOCK) void k_level_mat4(const FrameArgs a, cons
                 w = m4_mul(pm, l);
                 store_row<16>(a.world, e, w.v);
             } else {  // :69-72 world-edited entity: re-derive the local matrix
-                load_row<16>(a.world, e, w.v);
+                if (!SPEC) load_row<16>(a.world, e, w.v);
                 M4 inv;
                 if (!m4_inverse(pm, inv)) inv = m4_identity();
                 const M4 l = m4_mul(inv, w);
                 store_row<16>(const_cast<float*>(a.lmat), e, l.v);
             }
-        } else {
+        } else if (!SPEC) {
             load_row<16>(a.world, e, w.v);
         }
-        if (BOUNDS != 0) {
-            float b[6] = {0, 0, 0, 0, 0, 0};
-            uint32_t mesh = 0;
-            if (BOUNDS == 1) load_row<6, BIG>(a.bounds, e, b);
-            else mesh = a.mesh_id[e];
-            cull_entity<BOUNDS>(a, w, b, mesh, vmask, bmask);
-        }
+        if (BOUNDS != 0) cull_entity<BOUNDS>(a, w, b, mesh, vmask, bmask);
     }
     if (BOUNDS != 0) publish_visible(a, (uint32_t)(e64 >> 6), e64 - (tid & 63u) < a.begin, vmask, bmask);
 }

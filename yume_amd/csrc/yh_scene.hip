@@ -285,6 +285,7 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
     }
     if (const char* v = getenv("YH_NO_CULL_PLAN")) s->use_cull_plan = !(v[0] == '1');
     if (const char* v = getenv("YH_LDS_PARENTS")) s->lds_parents = v[0] == '1';
+    if (const char* v = getenv("YH_NO_SPEC")) s->spec_clean = !(v[0] == '1');
     if (const char* v = getenv("YH_BIG_TREE")) s->big_tree = strtoull(v, nullptr, 10);
     if (const char* v = getenv("YH_BIG_FLAT")) s->big_flat = strtoull(v, nullptr, 10);
     if (const char* v = getenv("YH_DEFER_FIRST_MAX")) s->defer_first_max = (uint32_t)strtoul(v, nullptr, 10);
