@@ -118,3 +118,28 @@ def test_structural_change_observers_of_the_gpu_system_inside_real_flecs(tmp_pat
     for name, want, got in rows:
         assert want == got, f"{name}: structure flag {got}, expected {want}"
     assert r.returncode == 0
+
+
+def test_host_data_structures_of_the_gpu_system(tmp_path):
+    """The partitioned map filled by helper threads (1, 4, 16), its reuse, small maps, and the radix sort of tables by
+    parent slot against qsort: tests/host_units_probe.c includes GpuTransformCullSystem.c and calls the static functions
+    as they are (CPU only)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flecs_o = os.path.join(root, "oracle", "_ref", "flecs.o")
+    flecs_h = "/root/reference/vendor/flecs"
+    lib = os.path.join(root, "yume_amd", "libyume_hip.so")
+    if not (os.path.exists(flecs_o) and os.path.exists(os.path.join(flecs_h, "flecs.h")) and os.path.exists(lib)):
+        pytest.skip("needs oracle/_ref/flecs.o (make -C oracle ref) and the reference's flecs.h")
+    exe = tmp_path / "units"
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Wno-unused-function", "-DFLECS_CONFIG_HEADER=1", "-I", flecs_h,
+                           "-I", os.path.join(root, "yume_amd", "host"), "-I", os.path.join(root, "include"), "-o", str(exe),
+                           os.path.join(root, "tests", "host_units_probe.c"), flecs_o, "-L", os.path.join(root, "yume_amd"),
+                           "-lyume_hip", f"-Wl,-rpath,{os.path.join(root, 'yume_amd')}", "-lm", "-lpthread"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    rows = [line.split() for line in r.stdout.splitlines()]
+    assert len(rows) == 6, r.stdout + r.stderr
+    for name, verdict in rows:
+        assert verdict == "ok", f"{name}: {verdict}"
+    assert r.returncode == 0
