@@ -156,57 +156,90 @@ def cpu_baseline(name, wl, n, lo, parent, planes, seconds):
     return out
 
 
-def cpu_baseline_flecs(lo_levels):
-    """The same rule driven by the REAL flecs 4.0.4 the reference vendors (oracle/_ref/flecs_harness, compiled from the
-    reference's flecs sources in place; the per-row arithmetic is the oracle's restatement: Zig cannot be built here).
-    Transform systems only (the reference has no cull), every LocalTransform dirty in frame 0, on a bounded sample.
-    The binary is a build artefact of the container that holds the reference: where it did not travel, the record
-    says so instead of silently vanishing."""
+def flecs_legs(lo_levels):
+    """The same rule driven by the REAL flecs 4.0.4 the reference vendors, twice on one bounded sample scene: the reference's
+    three CPU systems (oracle/_ref/flecs_harness: compiled from the reference's flecs sources in place; the per-row
+    arithmetic is the oracle's restatement, Zig cannot be built here; transform systems only, the reference has no cull)
+    and the drop-in (oracle/_ref/flecs_gpu_harness: yume_amd/host/GpuTransformCullSystem.c registered in the same flecs,
+    one frustum culled as well).  Frame 0: everything dirty (creation), frame 1: nothing moved, frames 2-4: the root is
+    re-set, so every WorldTransform row is recomputed (and, in the drop-in, crosses PCIe back into flecs' columns),
+    frame 5: nothing moved.  The binaries are build artefacts of the container that holds the reference: where they did
+    not travel, the records say so instead of silently vanishing.  Returns (cpu_baseline_in_flecs, dropin_in_flecs)."""
     import struct
     import subprocess
     import tempfile
 
     from oracle import pyoracle as oracle
 
-    exe = os.path.join(ROOT, "oracle", "_ref", "flecs_harness")
-    if not os.path.exists(exe):
-        return {"value": None, "kind": "reference-flecs", "sample": "oracle/_ref/flecs_harness is not on this box (it is built "
-                "from /root/reference/vendor/flecs by `make -C oracle ref` where the reference exists)"}
+    cpu_exe = os.path.join(ROOT, "oracle", "_ref", "flecs_harness")
+    gpu_exe = os.path.join(ROOT, "oracle", "_ref", "flecs_gpu_harness")
+    missing = ("is not on this box (it is built from /root/reference/vendor/flecs by `make -C oracle ref` where the "
+               "reference exists)")
     n_s = 200_000
     lo = oracle.synth_level_offsets(n_s, lo_levels)
     par = oracle.synth_parents(lo)
     local = oracle.compose_batch(oracle.synth_trs(n_s, int(lo[1])))
+    bounds = oracle.synth_aabb(n_s)
+    planes = oracle.main_camera_planes().reshape(1, 24)
     root = oracle.identity68()["m"][0]
     edit = np.asarray(oracle.compose([1, 2, 3], [0, 0, 0, 1], [1, 1, 1]), np.float32)
-    n_frames = 6  # frame 0: everything dirty (creation); then the root is re-set each frame: every row recomputes
+    frames = [0, 0, 1, 1, 1, 0]  # edits per frame: the root's WorldTransform is set in frames 2-4
+
+    def run(exe):
+        if not os.path.exists(exe):
+            return None, f"{os.path.relpath(exe, ROOT)} {missing}"
+        try:
+            r = subprocess.run([exe, scene, os.path.join(d, "out.bin")], capture_output=True, text=True, timeout=300,
+                               env=dict({k: v for k, v in os.environ.items() if not k.startswith("YFH_")}, YFH_TIMES="1"))
+        except Exception as ex:  # noqa: BLE001
+            return None, f"{os.path.basename(exe)} failed: {ex}"
+        ms = [float(line.split(": ")[1].split(" ms")[0]) for line in r.stderr.splitlines() if line.startswith("frame ")]
+        if len(ms) != len(frames):
+            return None, f"{os.path.basename(exe)} printed {len(ms)} frame times (rc {r.returncode})"
+        return ms, ""
+
     with tempfile.TemporaryDirectory() as d:
         scene = os.path.join(d, "scene.bin")
         with open(scene, "wb") as f:
-            f.write(b"YFH1")
-            f.write(struct.pack("<III", n_s, lo_levels, n_frames))
+            f.write(b"YFH2")
+            f.write(struct.pack("<III", n_s, lo_levels, len(frames)))
             f.write(lo.astype(np.uint32).tobytes())
             f.write(par.astype(np.uint32).tobytes())
             f.write(np.ascontiguousarray(local["m"], np.float32).tobytes())
             f.write(np.ascontiguousarray(root, np.float32).tobytes())
-            for k in range(n_frames):
-                if k == 0:
-                    f.write(struct.pack("<I", 0))
-                else:
-                    f.write(struct.pack("<III", 1, 0xFFFFFFFF, 1))
+            f.write(struct.pack("<I", planes.shape[0]))
+            f.write(np.ascontiguousarray(planes, np.float32).tobytes())
+            f.write(np.ascontiguousarray(bounds, np.float32).tobytes())
+            for k in frames:
+                f.write(struct.pack("<I", k))
+                if k:
+                    f.write(struct.pack("<II", 0xFFFFFFFF, 1))
                     f.write(edit.tobytes())
-        try:
-            r = subprocess.run([exe, scene, os.path.join(d, "out.bin")], env=dict(os.environ, YFH_TIMES="1"),
-                               capture_output=True, text=True, timeout=300)
-        except Exception as ex:  # noqa: BLE001
-            return {"value": None, "kind": "reference-flecs", "sample": f"flecs_harness failed: {ex}"}
-    ms = [float(line.split(": ")[1].split(" ms")[0]) for line in r.stderr.splitlines() if line.startswith("frame ")]
-    if len(ms) < 2:
-        return {"value": None, "kind": "reference-flecs", "sample": f"flecs_harness printed no frame times (rc {r.returncode})"}
-    med = float(np.median(ms[1:]))
-    return {"value": round(n_s / med / 1e3, 3), "unit": "Mentities/s", "cores": 1, "kind": "port",
-            "ns_per_entity": round(med * 1e6 / n_s, 2),
-            "sample": f"{len(ms) - 1} all-dirty frames of a {n_s}-entity {lo_levels}-level scene inside the reference's vendored "
-                      f"flecs 4.0.4 (TransformSyncSystem rule + both PostTransform sweeps, no cull; median)"}
+        cpu_ms, cpu_err = run(cpu_exe)
+        gpu_ms, gpu_err = run(gpu_exe)
+    what = f"a {n_s}-entity {lo_levels}-level scene inside the reference's vendored flecs 4.0.4"
+    if cpu_ms is None:
+        cpu = {"value": None, "kind": "reference-flecs", "sample": cpu_err}
+    else:
+        med = float(np.median(cpu_ms[2:5]))
+        cpu = {"value": round(n_s / med / 1e3, 3), "unit": "Mentities/s", "cores": 1, "kind": "port",
+               "ns_per_entity": round(med * 1e6 / n_s, 2), "ms_per_frame": [round(x, 3) for x in cpu_ms],
+               "sample": f"frames 2-4 (the root moved: every row recomputed) of {what} (TransformSyncSystem rule + both "
+                         f"PostTransform sweeps, no cull; median)"}
+    if gpu_ms is None:
+        dropin = {"value": None, "sample": gpu_err}
+    else:
+        med = float(np.median(gpu_ms[2:5]))
+        dropin = {"value": round(n_s / med / 1e3, 3), "unit": "Mentities/s", "ms_per_frame": [round(x, 3) for x in gpu_ms],
+                  "first_frame_ms": round(gpu_ms[0], 3), "nothing_moved_ms": round(min(gpu_ms[1], gpu_ms[5]), 3),
+                  "every_row_recomputed_ms": round(med, 3),
+                  "speedup_over_cpu_systems": {"every_row_recomputed": round(float(np.median(cpu_ms[2:5])) / med, 1),
+                                               "nothing_moved": round(min(cpu_ms[1], cpu_ms[5]) / min(gpu_ms[1], gpu_ms[5]), 1),
+                                               "first_frame": round(cpu_ms[0] / gpu_ms[0], 2)} if cpu_ms else None,
+                  "sample": f"GpuTransformCullSystem registered in the same flecs on the same scene, one frustum culled as well, "
+                            f"host wall time of the frame's systems (PCIe and the rows written back into flecs' columns "
+                            f"included): {what}"}
+    return cpu, dropin
 
 
 def profiled_traffic(workload, symbol):
@@ -742,7 +775,7 @@ def main():
                 result.update(legs)
             elif isinstance(result["workloads"].get(name), dict):
                 result["workloads"][name].update(legs)
-        result["cpu_baseline_in_flecs"] = cpu_baseline_flecs(8)
+        result["cpu_baseline_in_flecs"], result["dropin_in_flecs"] = flecs_legs(8)
     elif rank == 0:
         result["cpu_baseline"] = None
 
