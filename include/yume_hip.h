@@ -142,6 +142,12 @@ int yh_upload_hierarchy(yh_scene* s, const uint32_t* parent_index, const uint32_
  * All slots are alive until the first call.                                                                   */
 int yh_upload_parent_range(yh_scene* s, const uint32_t* parent_index, uint64_t first, uint64_t count);
 int yh_scene_set_alive_range(yh_scene* s, uint64_t first, uint64_t count, int alive);
+/* The same for many short runs or single slots in ONE call each (a burst of editor traffic touches thousands of flecs
+ * tables, Editor.zig:590-636; one blocking call per table and array cost ~0.15 ms a table).  Runs are applied in the order
+ * given.  yh_upload_parent_rows: slot slots[i] gets parent parent_index[i] (any levels; each parent inside the level before
+ * its slot's).  No counterpart in the reference: flecs keeps (ChildOf, parent) in the archetype.                        */
+int yh_scene_set_alive_runs(yh_scene* s, const uint32_t* first, const uint32_t* count, const uint8_t* alive, uint32_t n_runs);
+int yh_upload_parent_rows(yh_scene* s, const uint32_t* slots, const uint32_t* parent_index, uint64_t count);
 /* WorldTransform of the scene root (GameApp.zig:95); identity until set. */
 int yh_set_root(yh_scene* s, const float root_world[16]);
 /* The same from the root's 68-byte WorldTransform row as the `Up` term hands it to level-0 tables
@@ -170,6 +176,9 @@ int yh_upload_aabb(yh_scene* s, const float* const min_planes[3], const float* c
                    uint64_t first, uint64_t count);
 int yh_upload_mesh_aabbs(yh_scene* s, const float* table /* n_meshes x 6: min.xyz,max.xyz */, uint32_t n_meshes);
 int yh_upload_mesh_ids(yh_scene* s, const uint32_t* mesh_id, uint64_t first, uint64_t count);
+/* Single slots: slot slots[i] gets mesh_id[i] / the box min_max[6 i .. 6 i + 5] = {min.xyz, max.xyz} (meshes.zig:72-95).   */
+int yh_upload_mesh_id_rows(yh_scene* s, const uint32_t* slots, const uint32_t* mesh_id, uint64_t count);
+int yh_upload_aabb_rows(yh_scene* s, const uint32_t* slots, const float* min_max, uint64_t count);
 
 /* ---- per frame ----------------------------------------------------------------------------------------- */
 /* One pass of the hot path over the whole scene: compose -> level-ordered propagate -> cull + compact,

@@ -519,6 +519,138 @@ def test_spare_slots_dead_slots_and_a_moved_row(ctx, oracle):
         assert check("frame 3").size == 0
 
 
+def test_many_runs_and_single_slots_in_one_call_equal_the_range_calls(ctx, oracle):
+    """yh_scene_set_alive_runs / yh_upload_parent_rows / yh_upload_aabb_rows / yh_upload_mesh_id_rows (what a structural
+    patch of the drop-in uses when it touches thousands of tables) against the one-range-per-call entry points: two
+    scenes with spare slots get the same 700 moves - a leaf takes a spare slot of its level under another parent, its
+    old slot dies - one through the batched calls, one run by run; frames, draw lists, change lists, boxes and matrices
+    must be identical, and both equal the oracle.  Bad arguments are refused before anything is written."""
+    from yume_amd import Scene, _lib
+
+    n, levels, spare = 60_000, 6, 1000
+    lo, par, bounds, local, world = build(oracle, n, levels)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    root = oracle.identity68()
+    slot_lo = np.array([int(lo[k]) + k * spare for k in range(levels + 1)], np.uint32)
+    level_of = np.searchsorted(lo, np.arange(n), side="right") - 1
+    slot_of = (np.arange(n) + level_of * spare).astype(np.uint32)
+    N = int(slot_lo[-1])
+    spar = np.zeros(N, np.uint32)
+    spar[slot_of] = np.where(par == 0xFFFFFFFF, 0xFFFFFFFF, slot_of[np.minimum(par, n - 1)])
+    for k in range(levels):
+        dead = np.arange(int(lo[k + 1]) + k * spare, int(slot_lo[k + 1]))
+        spar[dead] = 0xFFFFFFFF if k == 0 else slot_lo[k - 1]
+    rng = np.random.default_rng(23)
+
+    def padded(col):
+        out = np.zeros(N, oracle.T68)
+        out[slot_of] = col
+        return out
+
+    # the moves: 700 leaves of the last two levels, each to a spare slot of its own level under a random parent
+    movers = np.concatenate([rng.choice(np.arange(int(lo[levels - 1]), n), 400, replace=False),
+                             rng.choice(np.arange(int(lo[levels - 2]), int(lo[levels - 1])), 300, replace=False)])
+    # (level levels-2 entities that move must have no children here: pick ones nobody names as parent)
+    movers = np.array([e for e in movers if not np.any(par == e)], np.int64)
+    new_par = np.array([rng.integers(int(lo[level_of[e] - 1]), int(lo[level_of[e]])) for e in movers])
+    next_spare = {k: int(lo[k + 1]) + k * spare for k in range(levels)}
+    new_slot = np.zeros(movers.size, np.uint32)
+    for i, e in enumerate(movers):
+        new_slot[i] = next_spare[level_of[e]]
+        next_spare[level_of[e]] += 1
+    old_slot = slot_of[movers].copy()
+
+    scenes = [Scene(ctx, N, n_levels=levels, n_frusta=1, local_kind=_lib.YH_LOCAL_MAT4) for _ in range(2)]
+    try:
+        b = np.zeros((N, 6), np.float32)
+        b[slot_of] = bounds
+        for s in scenes:
+            s.upload_hierarchy(spar, slot_lo)
+            s.upload_aabb(np.ascontiguousarray(b[:, 0:3].T), np.ascontiguousarray(b[:, 3:6].T))
+            s.upload_local_aos68(padded(local))
+            s.upload_world_aos68(padded(world))
+            s.track_changes(True)
+        batched, ranged = scenes
+        # dead spare slots: one call against one per level
+        firsts = np.array([int(lo[k + 1]) + k * spare for k in range(levels)], np.uint32)
+        batched.set_alive_runs(firsts, np.full(levels, spare, np.uint32), np.zeros(levels, np.uint8))
+        for f in firsts:
+            ranged.set_alive_range(int(f), spare, False)
+        with pytest.raises(_lib.YumeHipError) as e:
+            batched.set_alive_runs([N - 1], [2], [0])
+        assert e.value.code == _lib.YH_ERR_BAD_ARG
+        with pytest.raises(_lib.YumeHipError) as e:  # a parent from the wrong level: nothing is written
+            batched.upload_parent_rows([int(new_slot[0]), int(new_slot[1])], [int(slot_of[new_par[0]]), int(slot_of[0])])
+        assert e.value.code == _lib.YH_ERR_BAD_ARG
+        with pytest.raises(_lib.YumeHipError) as e:
+            batched.upload_aabb_rows([N], np.zeros((1, 6), np.float32))
+        assert e.value.code == _lib.YH_ERR_BAD_ARG
+        for s in scenes:
+            s.frame(planes, flags=0)
+        oracle.frame_aos68(world, local, par, lo, root)  # frame 0: everything dirty
+        # the moves
+        par[movers] = new_par
+        slot_of[movers] = new_slot
+        local["dirty"][movers] = 1
+        rows_l, rows_w = local[movers], world[movers]
+        batched.set_alive_runs(np.concatenate([old_slot, new_slot]), np.ones(2 * movers.size, np.uint32),
+                               np.concatenate([np.zeros(movers.size, np.uint8), np.ones(movers.size, np.uint8)]))
+        batched.upload_parent_rows(new_slot, slot_of[new_par])
+        batched.upload_aabb_rows(new_slot, bounds[movers])
+        batched.upload_local_rows(new_slot, rows_l)
+        batched.upload_world_rows(new_slot, rows_w)
+        for i, e_ in enumerate(movers):
+            ranged.set_alive_range(int(old_slot[i]), 1, False)
+            ranged.set_alive_range(int(new_slot[i]), 1, True)
+            ranged.upload_parent_range(np.array([slot_of[new_par[i]]], np.uint32), int(new_slot[i]))
+            ranged.upload_aabb(np.ascontiguousarray(bounds[e_:e_ + 1, 0:3].T), np.ascontiguousarray(bounds[e_:e_ + 1, 3:6].T), first=int(new_slot[i]))
+            ranged.upload_local_aos68(local[e_:e_ + 1], first=int(new_slot[i]))
+            ranged.upload_world_aos68(world[e_:e_ + 1], first=int(new_slot[i]))
+        for fi in range(2):
+            oracle.frame_aos68(world, local, par, lo, root)
+            for s in scenes:
+                s.frame(planes, flags=0)
+            vis, _ = oracle.cull(world, bounds, planes, n_threads=4)
+            lists = [s.draw_list(0) for s in scenes]
+            assert np.array_equal(lists[0], lists[1]), f"frame {fi + 1}: draw lists of the two scenes"
+            assert np.array_equal(lists[0], np.sort(slot_of[np.flatnonzero(vis[0])])), f"frame {fi + 1}: against the oracle"
+            cw = [s.changed_rows(0)[0] for s in scenes]
+            assert np.array_equal(cw[0], cw[1]), f"frame {fi + 1}: change lists"
+            if fi == 0:
+                assert np.array_equal(np.sort(cw[0]), np.sort(new_slot)), "exactly the moved rows were recomputed"
+            dev = [s.world_aos68() for s in scenes]
+            assert_same_values(dev[0]["m"][slot_of], world["m"], f"frame {fi + 1}: world, batched")
+            assert_same_values(dev[1]["m"][slot_of], world["m"], f"frame {fi + 1}: world, ranged")
+        mn0, mx0 = batched.download_aabb()
+        mn1, mx1 = ranged.download_aabb()
+        assert np.array_equal(mn0[:, slot_of], mn1[:, slot_of]) and np.array_equal(mx0[:, slot_of], mx1[:, slot_of])
+    finally:
+        for s in scenes:
+            s.close()
+
+    # mesh-table scenes: ids of single slots
+    nm = 16  # (fill_synthetic hands out ids 0 .. 15)
+    with Scene(ctx, 5000, n_frusta=1, bounds_kind=2, max_meshes=16) as a, Scene(ctx, 5000, n_frusta=1, bounds_kind=2, max_meshes=16) as c:
+        table = rng.uniform(-2, 2, (nm, 6)).astype(np.float32)
+        table[:, 3:] = np.abs(table[:, 3:]) + 0.1
+        table[:, :3] = -np.abs(table[:, :3]) - 0.1
+        ids = rng.integers(0, nm, 5000).astype(np.uint32)
+        sl = rng.choice(5000, 1200, replace=False).astype(np.uint32)
+        for s in (a, c):
+            s.upload_flat()
+            s.fill_synthetic()
+            s.upload_mesh_aabbs(table)
+        a.upload_mesh_id_rows(sl, ids[sl])
+        for e_ in sl:
+            c.upload_mesh_ids(ids[e_:e_ + 1], first=int(e_))
+        with pytest.raises(_lib.YumeHipError) as e:
+            a.upload_mesh_id_rows([3], [nm])
+        assert e.value.code == _lib.YH_ERR_BAD_ARG
+        for s in (a, c):
+            s.frame(planes)
+        assert np.array_equal(a.draw_list(0), c.draw_list(0))
+
+
 def test_rows_change_slots_on_the_device(ctx, oracle):
     """yh_move_rows: both rows of src[i], flags included, become the rows of dst[i]; sources are read before any
     destination is written (a rotation: every destination is another pair's source), rows outside dst keep theirs;

@@ -122,6 +122,10 @@ SIGNATURES = {
     "yh_download_changed_aos68": (_int, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     "yh_upload_parent_range": (_int, [_vp, _vp, _u64, _u64]),
     "yh_scene_set_alive_range": (_int, [_vp, _u64, _u64, _int]),
+    "yh_scene_set_alive_runs": (_int, [_vp, _vp, _vp, _vp, _u32]),
+    "yh_upload_parent_rows": (_int, [_vp, _vp, _vp, _u64]),
+    "yh_upload_mesh_id_rows": (_int, [_vp, _vp, _vp, _u64]),
+    "yh_upload_aabb_rows": (_int, [_vp, _vp, _vp, _u64]),
     "yh_get_changed_counts": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "yh_download_changed_rows_aos68": (_int, [_vp, _int, _vp, _vp, _u64, C.POINTER(_u64), _vp, _vp]),
     "yh_upload_vertex_counts": (_int, [_vp, _vp, _u64]),

@@ -342,6 +342,34 @@ class Scene:
         """Slots that hold no entity are never visible and never reported as changed (Mat4 scenes)."""
         self._ck(L.lib().yh_scene_set_alive_range(self._h, first, count, int(bool(alive))))
 
+    def set_alive_runs(self, first, count, alive):
+        """The same for many runs in one call, applied in the order given."""
+        first = np.ascontiguousarray(first, np.uint32)
+        count = np.ascontiguousarray(count, np.uint32)
+        alive = np.ascontiguousarray(alive, np.uint8)
+        assert first.size == count.size == alive.size
+        self._ck(L.lib().yh_scene_set_alive_runs(self._h, _ptr(first), _ptr(count), _ptr(alive), first.size))
+
+    def upload_parent_rows(self, slots, parents):
+        """Parent indices of single slots (any levels)."""
+        slots = np.ascontiguousarray(slots, np.uint32)
+        parents = np.ascontiguousarray(parents, np.uint32)
+        assert slots.size == parents.size
+        self._ck(L.lib().yh_upload_parent_rows(self._h, _ptr(slots), _ptr(parents), slots.size))
+
+    def upload_mesh_id_rows(self, slots, ids):
+        slots = np.ascontiguousarray(slots, np.uint32)
+        ids = np.ascontiguousarray(ids, np.uint32)
+        assert slots.size == ids.size
+        self._ck(L.lib().yh_upload_mesh_id_rows(self._h, _ptr(slots), _ptr(ids), slots.size))
+
+    def upload_aabb_rows(self, slots, min_max):
+        """Boxes of single slots: min_max is (len(slots), 6) = min.xyz, max.xyz."""
+        slots = np.ascontiguousarray(slots, np.uint32)
+        min_max = np.ascontiguousarray(min_max, np.float32).reshape(-1, 6)
+        assert slots.size == min_max.shape[0]
+        self._ck(L.lib().yh_upload_aabb_rows(self._h, _ptr(slots), _ptr(min_max), slots.size))
+
     def changed_counts(self):
         """(rows whose WorldTransform changed, rows whose LocalTransform changed) in the last tracked frame."""
         nw, nl = C.c_uint64(), C.c_uint64()

@@ -899,6 +899,20 @@ __global__ __launch_bounds__(YH_BLOCK) void k_stream_probe(const float4* __restr
 }
 
 // Fill plane q of a chunked array with a constant (scene creation: world = IDENTITY).
+// sparse updates of per-slot words and boxes (yh_upload_parent_rows / _mesh_id_rows / _aabb_rows): value i goes to slot slots[i]
+__global__ __launch_bounds__(YH_BLOCK) void k_scatter_u32(uint32_t* __restrict__ dst, const uint32_t* __restrict__ slots,
+                                                          const uint32_t* __restrict__ vals, uint64_t m) {
+    const uint64_t i = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;
+    if (i < m) dst[slots[i]] = vals[i];
+}
+__global__ __launch_bounds__(YH_BLOCK) void k_scatter_aabb(float* __restrict__ bounds, const uint32_t* __restrict__ slots,
+                                                           const float* __restrict__ mm /* m x {min.xyz, max.xyz} */, uint64_t m) {
+    const uint64_t i = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t off = eoff<6>(slots[i]);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) *reinterpret_cast<float*>(reinterpret_cast<char*>(bounds) + off + q * 256) = mm[i * 6 + q];
+}
 __global__ __launch_bounds__(YH_BLOCK) void k_fill_plane(float* __restrict__ arr, uint32_t np, uint32_t q, float v,
                                                          uint64_t n) {
     const uint64_t e = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;

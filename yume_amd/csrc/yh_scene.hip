@@ -631,6 +631,125 @@ extern "C" int yh_upload_mesh_ids(yh_scene* s, const uint32_t* mesh_id, uint64_t
     return YH_OK;
 }
 
+// ---- the same updates for MANY short runs at once (a structural patch of the drop-in touches thousands of tables: one
+// blocking call per table and array was ~0.15 ms a table) -------------------------------------------------------------
+extern "C" int yh_scene_set_alive_runs(yh_scene* s, const uint32_t* first, const uint32_t* count, const uint8_t* alive, uint32_t n_runs) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_scene_set_alive_runs: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    if (n_runs == 0) return YH_OK;
+    ARG_TRY(ctx, first && count && alive, "yh_scene_set_alive_runs: NULL argument");
+    if (s->desc.local_kind != YH_LOCAL_MAT4)
+        return fail(ctx, YH_ERR_STATE, "yh_scene_set_alive_runs: TRS scenes have no spare slots (every slot is an instance)");
+    for (uint32_t r = 0; r < n_runs; ++r)
+        if ((uint64_t)first[r] + count[r] > s->n)
+            return fail(ctx, YH_ERR_BAD_ARG, "yh_scene_set_alive_runs: run %u [%u, +%u) leaves the scene's %llu slots", r, first[r], count[r],
+                        (unsigned long long)s->n);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_scene(s)) return rc;
+    if (!s->alive) {
+        s->h_alive.assign(s->n_chunks, ~0ull);
+        if (s->n & 63u) s->h_alive.back() = (1ull << (s->n & 63u)) - 1ull;
+        HIP_TRY(ctx, hipMalloc((void**)&s->alive, (uint64_t)s->n_chunks * 8));
+        HIP_TRY(ctx, hipMemcpy(s->alive, s->h_alive.data(), (uint64_t)s->n_chunks * 8, hipMemcpyHostToDevice));
+    }
+    uint64_t lo_c = ~0ull, hi_c = 0;
+    for (uint32_t r = 0; r < n_runs; ++r) {  // in the order given: a later run overrides an earlier one where they overlap
+        if (!count[r]) continue;
+        const uint64_t f = first[r], c0 = f >> 6, c1 = (f + count[r] - 1) >> 6;
+        for (uint64_t c = c0; c <= c1; ++c) {
+            const uint64_t lo = c == c0 ? (f & 63u) : 0u, hi = c == c1 ? ((f + count[r] - 1) & 63u) : 63u;
+            const uint64_t bits = (hi == 63u ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull);
+            if (alive[r]) s->h_alive[c] |= bits;
+            else s->h_alive[c] &= ~bits;
+        }
+        lo_c = std::min(lo_c, c0);
+        hi_c = std::max(hi_c, c1);
+    }
+    if (lo_c <= hi_c) HIP_TRY(ctx, hipMemcpy(s->alive + lo_c, s->h_alive.data() + lo_c, (hi_c - lo_c + 1) * 8, hipMemcpyHostToDevice));
+    return YH_OK;
+}
+
+// slots + values to the staging area, one scatter launch; returns with the copy done (the host arrays are the caller's again)
+static int scatter_words(yh_scene* s, uint32_t* dst, const uint32_t* slots, const uint32_t* vals, uint64_t count) {
+    yh_ctx* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_scene(s)) return rc;  // frames in flight still read the old values
+    if (int rc = ensure_staging(s, count * 8)) return rc;
+    uint32_t* d_slots = (uint32_t*)s->staging;
+    uint32_t* d_vals = d_slots + count;
+    HIP_TRY(ctx, hipMemcpyAsync(d_slots, slots, count * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_vals, vals, count * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_scatter_u32, dim3((uint32_t)cdiv(count, YH_BLOCK)), dim3(YH_BLOCK), 0, ctx->stream, dst, d_slots, d_vals, count);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return YH_OK;
+}
+
+// Parent indices of single slots (any levels): slot slots[i] gets parent parent_index[i], which must lie in the level
+// before the slot's own (level-0 slots: value unused).  Should a slot be named twice, either value may win.
+extern "C" int yh_upload_parent_rows(yh_scene* s, const uint32_t* slots, const uint32_t* parent_index, uint64_t count) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_upload_parent_rows: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    if (count == 0) return YH_OK;
+    ARG_TRY(ctx, slots && parent_index, "yh_upload_parent_rows: NULL argument");
+    if (!s->have_hierarchy) return fail(ctx, YH_ERR_STATE, "yh_upload_parent_rows: call yh_upload_hierarchy first");
+    const uint32_t L = s->desc.n_levels;
+    uint32_t k = 0;
+    for (uint64_t i = 0; i < count; ++i) {
+        const uint32_t e = slots[i];
+        if (e >= s->n) return fail(ctx, YH_ERR_BAD_ARG, "yh_upload_parent_rows: slot %u at %llu >= n_entities", e, (unsigned long long)i);
+        if (!(e >= s->level_offsets[k] && e < s->level_offsets[k + 1])) {  // (runs of slots of one level: the last level found is tried first)
+            k = 0;
+            while (k + 1 < L && s->level_offsets[k + 1] <= e) ++k;
+        }
+        const uint32_t p = parent_index[i];
+        if (k > 0 && !(p >= s->level_offsets[k - 1] && p < s->level_offsets[k]))
+            return fail(ctx, YH_ERR_BAD_ARG, "yh_upload_parent_rows: slot %u (level %u) has parent %u outside level %u", e, k, p, k - 1);
+    }
+    return scatter_words(s, s->parent, slots, parent_index, count);
+}
+
+extern "C" int yh_upload_mesh_id_rows(yh_scene* s, const uint32_t* slots, const uint32_t* mesh_id, uint64_t count) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_upload_mesh_id_rows: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    if (count == 0) return YH_OK;
+    ARG_TRY(ctx, slots && mesh_id, "yh_upload_mesh_id_rows: NULL argument");
+    if (s->desc.bounds_kind != YH_BOUNDS_MESH_TABLE) return fail(ctx, YH_ERR_STATE, "yh_upload_mesh_id_rows: scene has no mesh table");
+    ARG_TRY(ctx, s->n_meshes >= 1, "yh_upload_mesh_id_rows: upload the mesh table first");
+    uint32_t top = 0;
+    for (uint64_t i = 0; i < count; ++i) {
+        if (slots[i] >= s->n) return fail(ctx, YH_ERR_BAD_ARG, "yh_upload_mesh_id_rows: slot %u at %llu >= n_entities", slots[i], (unsigned long long)i);
+        if (mesh_id[i] >= s->n_meshes)
+            return fail(ctx, YH_ERR_BAD_ARG, "yh_upload_mesh_id_rows: id %u at %llu >= n_meshes %u", mesh_id[i], (unsigned long long)i, s->n_meshes);
+        top = std::max(top, mesh_id[i]);
+    }
+    if (int rc = scatter_words(s, s->mesh_id, slots, mesh_id, count)) return rc;
+    s->max_mesh_id = std::max(s->max_mesh_id, top);
+    return YH_OK;
+}
+
+// Per-entity boxes of single slots: min_max holds count x {min.x, min.y, min.z, max.x, max.y, max.z}.
+extern "C" int yh_upload_aabb_rows(yh_scene* s, const uint32_t* slots, const float* min_max, uint64_t count) {
+    if (!s) return fail(nullptr, YH_ERR_BAD_ARG, "yh_upload_aabb_rows: scene is NULL");
+    yh_ctx* ctx = s->ctx;
+    if (count == 0) return YH_OK;
+    ARG_TRY(ctx, slots && min_max, "yh_upload_aabb_rows: NULL argument");
+    if (s->desc.bounds_kind != YH_BOUNDS_PER_ENTITY) return fail(ctx, YH_ERR_STATE, "yh_upload_aabb_rows: scene has no per-entity bounds");
+    for (uint64_t i = 0; i < count; ++i)
+        if (slots[i] >= s->n) return fail(ctx, YH_ERR_BAD_ARG, "yh_upload_aabb_rows: slot %u at %llu >= n_entities", slots[i], (unsigned long long)i);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_scene(s)) return rc;
+    if (int rc = ensure_staging(s, count * 28)) return rc;
+    float* d_mm = (float*)s->staging;
+    uint32_t* d_slots = (uint32_t*)(d_mm + count * 6);
+    HIP_TRY(ctx, hipMemcpyAsync(d_mm, min_max, count * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_slots, slots, count * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_scatter_aabb, dim3((uint32_t)cdiv(count, YH_BLOCK)), dim3(YH_BLOCK), 0, ctx->stream, s->bounds, d_slots, d_mm, count);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return YH_OK;
+}
+
 int ensure_staging(yh_scene* s, uint64_t bytes) {
     if (s->staging_bytes >= bytes) return YH_OK;
     if (s->staging) HIP_TRY(s->ctx, hipFree(s->staging));
