@@ -179,6 +179,7 @@ struct GpuTransformCullSystem {
     ecs_table_t** deleted;        /* tables with one of the components deleted since the last frame: their batches die */
     uint32_t n_deleted, cap_deleted;
     int need_full;                /* an event patch() cannot follow: a table deleted, too many tables touched */
+    int slots_untrusted;          /* a patch failed half-way: entity_of_slot / slot_of / the device rows disagree until the next rebuild */
     int walk_cache_valid;         /* cached_* describe the batches (false after a patch: the next walk rebuilds) */
     uint32_t* cached_slot;        /* per batch: slot_begin and parent_slot as the last rebuild assigned them */
     uint64_t slot_entries;        /* entries put into slot_of (stale ones stay until the next rebuild) */
@@ -285,6 +286,7 @@ static void run(ecs_iter_t* it) {
             clean = 1;
             patched_rows_up = s->last_up_rows;
         } else if (rc < 0) { /* half-done: nothing of the cached state is trusted any more */
+            s->slots_untrusted = 1; /* (nor the slot -> entity table: see the rebuild below) */
             s->need_full = 1;
             s->structure_dirty = 1;
             s->walk_cache_valid = 0;
@@ -333,10 +335,16 @@ static void run(ecs_iter_t* it) {
         }
         if (!rebuilt) restore_slots(s);
         else {
-            if (s->host_stale && s->scene && (rc = catch_up_by_entity(s)) != YH_OK) {
+            if (s->host_stale && s->scene && s->slots_untrusted) {
+                /* A patch failed half-way (a device error) while flecs' columns were behind the device: slot -> entity is
+                 * partly rewritten, so bringing rows home through it could hand an entity another one's matrices.  The rows
+                 * computed on the device since readback was switched off are given up; flecs' own copies go up again. */
+                s->host_stale = 0;
+            } else if (s->host_stale && s->scene && (rc = catch_up_by_entity(s)) != YH_OK) {
                 s->status = rc;
                 return;
             }
+            s->slots_untrusted = 0;
             const double t_rebuild = now_ms();
             rc = rebuild(s);
             s->last_ms[5] = now_ms() - t_rebuild;

@@ -110,7 +110,10 @@ yh_scene* GpuTransformCullSystem_scene(GpuTransformCullSystem* s);
 /* Visible entities of the last frame for one frustum, ascending slot order.  Returns the count; writes at most cap. */
 uint64_t GpuTransformCullSystem_visible(GpuTransformCullSystem* s, uint32_t frustum, ecs_entity_t* out, uint64_t cap);
 
-/* Last error code of the per-frame run (0 = ok): system callbacks cannot return one. */
+/* Last error code of the per-frame run (0 = ok): system callbacks cannot return one.  A negative status means the frame
+ * wrote nothing back; the next frame walks the query and rebuilds from flecs' columns.  If results were being left on the
+ * device (setReadback(s, 0)) and the failure struck while a structural change was being patched in, the rows computed on the
+ * device since readback was switched off are given up (the half-rewritten slot table is not read). */
 int GpuTransformCullSystem_status(const GpuTransformCullSystem* s);
 uint64_t GpuTransformCullSystem_entities(const GpuTransformCullSystem* s);
 uint32_t GpuTransformCullSystem_levels(const GpuTransformCullSystem* s); /* levels of the device scene (the spare ones included) */
