@@ -1033,3 +1033,75 @@ def test_dead_slots_are_reused_by_later_patches(oracle, tmp_path):
         exp_vis, _ = oracle.cull(np.ascontiguousarray(cw), bounds, planes)
         assert np.array_equal(np.sort(vis[0]), np.flatnonzero(exp_vis[0])), f"frame {fi}: visible set"
     assert gpu[-1][2] == 1 and gpu[-1][4][-1][4] == 40, f"rebuilds {gpu[-1][2]}, (up, down, walks, skipped, patches) {gpu[-1][4][-1]}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["readback", "no-readback", "ecs-inputs"])
+def test_a_patch_of_hundreds_of_tables_goes_up_in_one_call_per_array(oracle, tmp_path, mode):
+    """Editor traffic in bulk: 700 leaves re-parented in one frame (1400 tables touched: above the 256 from which a patch
+    takes its level's untouched tail first), then 500 of them deleted and matrices edited, then 400 entities created under
+    as many parents.  Each such frame is ONE patch whose alive runs, rows, boxes or mesh ids and parent indices travel in one
+    library call per array; rows and visible sets equal the CPU systems' every frame.  "no-readback": the rows change
+    slots on the device (yh_move_rows), flecs' columns are compared once the last frame has brought them home."""
+    n0, levels, extra = 60_000, 6, 400
+    n = n0 + extra
+    rng = np.random.default_rng(77)
+    lo0 = oracle.synth_level_offsets(n0, levels)
+    par0 = oracle.synth_parents(lo0)
+    lo = np.concatenate([lo0, [n]]).astype(np.uint32)  # the harness only sizes arrays with it
+    parent = np.concatenate([par0, np.full(extra, 0xFFFFFFFE, np.uint32)])  # the extra entities are created by edits (kind 6)
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo0[1])))
+    bounds = oracle.synth_aabb(n)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+
+    def rnd_m(scale=5.0):
+        return oracle.compose(rng.uniform(-scale, scale, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+
+    last = np.arange(int(lo0[-2]), n0)
+    movers = rng.choice(last, 700, replace=False)
+    new_par = rng.integers(int(lo0[-3]), int(lo0[-2]), movers.size)
+    doomed = movers[:500]
+    born = np.arange(n0, n)
+    born_par = rng.choice(np.arange(int(lo0[-3]), int(lo0[-2])), extra, replace=False)
+    frames = [
+        [],
+        [(int(e), 3, reparent_arg(int(p))) for e, p in zip(movers, new_par)],
+        [(int(e), 2, np.zeros(16, np.float32)) for e in doomed] + [(int(e), 0, rnd_m()) for e in rng.choice(int(lo0[-2]), 300, replace=False)],
+        [(int(e), 6, reparent_arg(int(p))) for e, p in zip(born, born_par)],
+        [(int(e), 1, rnd_m(30.0)) for e in born[:50]],
+        [],
+    ]
+    scene, out_c, out_g = tmp_path / "scene.bin", tmp_path / "cpu.bin", tmp_path / "gpu.bin"
+    write_scene(scene, lo, parent, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
+    subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
+    if mode == "no-readback":
+        env["YFH_READBACK_OFF_FROM"] = "1"
+    if mode == "ecs-inputs":
+        env["YFH_ECS_INPUTS"] = "1"
+    subprocess.check_call([GPU, str(scene), str(out_g)], timeout=300, env=env)
+    nf = 2 if mode == "ecs-inputs" else 1
+    cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
+    gpu = read_out(out_g, n, len(frames), nf, oracle.T68, gpu=True)
+    cull_bounds, cull_planes = bounds, planes
+    if mode == "ecs-inputs":
+        from yume_amd import synth
+
+        box = {0: [0, 0, 0, 0, 0, 0]}
+        for k in (1, 2, 3):
+            box[k] = [-0.5 * k, -0.25 * k - 0.5, -1.0, 0.5 * k, 0.25 * k + 0.5, 1.5]
+        cull_bounds = np.array([box[e % 4] for e in range(n)], np.float32)
+        cull_planes = np.stack([synth.main_camera_planes(), synth.cascade_planes()[1]]).astype(np.float32).reshape(2, 24)
+    for fi, ((cw, cl, _, rows, _), (gw, gl, rebuilds, g_rows, vis)) in enumerate(zip(cpu, gpu)):
+        stats = f"(rows up, rows down, walks, skipped, patches) = {vis[-1]}, rebuilds {rebuilds}"
+        host_current = mode != "no-readback" or fi == 0 or fi + 1 == len(frames)
+        if host_current:
+            with np.errstate(all="ignore"):
+                assert np.array_equal(gw["m"], cw["m"], equal_nan=True) and np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi} {stats}"
+            assert np.array_equal(gw["dirty"], cw["dirty"]) and np.array_equal(gl["dirty"], cl["dirty"]), f"frame {fi}: dirty bytes {stats}"
+        assert g_rows == rows, f"frame {fi}: {g_rows} rows on the device, {rows} in the CPU systems {stats}"
+        here = np.flatnonzero(cw["m"].any(axis=1) | cl["m"].any(axis=1))
+        exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[here]), np.ascontiguousarray(cull_bounds[here]), cull_planes)
+        for f in range(cull_planes.shape[0]):
+            assert np.array_equal(np.sort(vis[f]), here[np.flatnonzero(exp_vis[f])]), f"frame {fi} frustum {f}: visible set {stats}"
+    assert gpu[-1][2] == 1 and gpu[-1][4][-1][4] == 3, f"three patched frames, no rebuild: {gpu[-1][4][-1]}, rebuilds {gpu[-1][2]}"
