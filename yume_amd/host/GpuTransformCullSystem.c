@@ -111,6 +111,8 @@ struct GpuTransformCullSystem {
     BoundsEntry* bounds;
     uint64_t bounds_cap, bounds_n;
     int bounds_stale;
+    ecs_entity_t* mesh_dirty; /* entities whose Mesh / Material was set since the last frame (mesh-table scenes) */
+    uint64_t n_mesh_dirty, cap_mesh_dirty;
 
     float planes[YH_MAX_FRUSTA * 24];
     uint32_t n_frusta;
@@ -368,7 +370,8 @@ static void run(ecs_iter_t* it) {
         s->root = root;
         s->batches_live = 1;
     }
-    if (s->bounds_stale && (rc = upload_bounds(s)) != YH_OK) {
+    if (s->bounds_stale) s->n_mesh_dirty = 0; /* (every id is read afresh) */
+    if ((s->bounds_stale && (rc = upload_bounds(s)) != YH_OK) || (s->n_mesh_dirty && (rc = mesh_ids_refresh(s)) != YH_OK)) {
         s->status = rc;
         return;
     }
@@ -668,7 +671,32 @@ int GpuTransformCullSystem_setTrustObservers(GpuTransformCullSystem* s, int on) 
     return YH_OK;
 }
 
-static void note_mesh_set(ecs_iter_t* it) { ((GpuTransformCullSystem*)it->ctx)->bounds_stale = 1; }
+/* OnSet of Mesh / Material: the keys of those entities go stale.  A few of them are re-read one by one before the next
+ * frame (mesh_ids_refresh); while every id is due to be read afresh anyway, or once there are too many, nothing is listed. */
+#define MESH_DIRTY_MAX 65536u
+static void note_mesh_set(ecs_iter_t* it) {
+    GpuTransformCullSystem* s = (GpuTransformCullSystem*)it->ctx;
+    if (s->bounds_stale) return;
+    if (s->n_mesh_dirty + (uint64_t)it->count > MESH_DIRTY_MAX) {
+        s->bounds_stale = 1;
+        s->n_mesh_dirty = 0;
+        return;
+    }
+    if (s->n_mesh_dirty + (uint64_t)it->count > s->cap_mesh_dirty) {
+        uint64_t cap = s->cap_mesh_dirty ? s->cap_mesh_dirty * 2 : 256;
+        while (cap < s->n_mesh_dirty + (uint64_t)it->count) cap *= 2;
+        ecs_entity_t* d = (ecs_entity_t*)realloc(s->mesh_dirty, cap * sizeof(ecs_entity_t));
+        if (!d) {
+            s->bounds_stale = 1;
+            s->n_mesh_dirty = 0;
+            return;
+        }
+        s->mesh_dirty = d;
+        s->cap_mesh_dirty = cap;
+    }
+    memcpy(s->mesh_dirty + s->n_mesh_dirty, it->entities, sizeof(ecs_entity_t) * (size_t)it->count);
+    s->n_mesh_dirty += (uint64_t)it->count;
+}
 
 int GpuTransformCullSystem_setCameraComponent(GpuTransformCullSystem* s, ecs_entity_t camera, uint32_t view_projection_offset) {
     if (!s || !camera) return YH_ERR_BAD_ARG;
@@ -863,6 +891,7 @@ void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     if (s->camera_query) ecs_query_fini(s->camera_query);
     free(s->batches);
     free(s->walk_entities);
+    free(s->mesh_dirty);
     free(s->cached_entities);
     free(s->cached_src);
     free(s->cached_counts);
