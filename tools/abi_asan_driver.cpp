@@ -105,6 +105,12 @@ int main() {
         memcpy(m0, col.data() + 68 * 777, 64);
         for (int q = 0; q < 16; ++q) EXPECT(m0[q] == soa[(size_t)q * n + 777]);
         CK(yh_download_world_aos68(s, col.data(), 5, 1000));
+        {   // boxes of single slots
+            const uint32_t sl[2] = {3, n - 1}, bad[1] = {n};
+            const float mm[12] = {-1, -1, -1, 1, 1, 1, -2, -2, -2, 2, 2, 2};
+            CK(yh_upload_aabb_rows(s, sl, mm, 2));
+            EXPECT(yh_upload_aabb_rows(s, bad, mm, 1) == YH_ERR_BAD_ARG);
+        }
         // consumers
         std::vector<uint32_t> vc(n, 36);
         CK(yh_upload_vertex_counts(s, vc.data(), n));
@@ -162,6 +168,11 @@ int main() {
         std::vector<uint32_t> vcount(nm);
         for (uint32_t m = 0; m < nm; ++m) vcount[m] = 3 * (m + 1);
         CK(yh_upload_vertex_counts(s, vcount.data(), nm));
+        {   // mesh ids of single slots
+            const uint32_t sl[3] = {0, 17, n - 1}, ids[3] = {nm - 1, 0, 3}, big[3] = {0, nm, 1};
+            CK(yh_upload_mesh_id_rows(s, sl, ids, 3));
+            EXPECT(yh_upload_mesh_id_rows(s, sl, big, 3) == YH_ERR_BAD_ARG);
+        }
         CK(yh_frame(s, planes, 1, YH_FRAME_ALL_DIRTY));
         uint32_t counts[8], bc[8];
         CK(yh_get_counts(s, counts, bc));
@@ -239,6 +250,20 @@ int main() {
             for (int i = 0; i < 3; ++i) EXPECT(memcmp(&after[dst[i] * 68], &before[src[i] * 68], 64) == 0);
             EXPECT(yh_move_rows(s, bad, dst, 1) == YH_ERR_BAD_ARG);
             CK(yh_move_rows(s, nullptr, nullptr, 0));
+        }
+        {   // many runs / single slots in one call each (what a structural patch of the drop-in uses), and refused arguments
+            const uint32_t rf[3] = {n - 4, n - 2, n - 4}, rn[3] = {3, 2, 1};
+            const uint8_t ra[3] = {0, 0, 1};
+            CK(yh_scene_set_alive_runs(s, rf, rn, ra, 3));
+            const uint32_t bf[1] = {n - 1}, bc[1] = {2};
+            EXPECT(yh_scene_set_alive_runs(s, bf, bc, ra, 1) == YH_ERR_BAD_ARG);
+            CK(yh_scene_set_alive_runs(s, nullptr, nullptr, nullptr, 0));
+            const uint32_t ps[2] = {lo[1] + 1, lo[2] + 3}, pv[2] = {lo[0] + 1, lo[1] + 2}, wrong[2] = {lo[0] + 1, lo[0]};
+            CK(yh_upload_parent_rows(s, ps, pv, 2));
+            EXPECT(yh_upload_parent_rows(s, ps, wrong, 2) == YH_ERR_BAD_ARG);  // slot of level 2 with a parent of level 0
+            EXPECT(yh_upload_mesh_id_rows(s, ps, pv, 2) == YH_ERR_STATE);        // no mesh table in this scene
+            EXPECT(yh_upload_aabb_rows(s, ps, root, 1) == YH_ERR_STATE);          // nor per-entity boxes
+            CK(yh_frame(s, nullptr, 0, 0));
         }
         yh_scene_destroy(s);
     }
