@@ -186,6 +186,9 @@ struct GpuTransformCullSystem {
     uint32_t* cached_slot;        /* per batch: slot_begin and parent_slot as the last rebuild assigned them */
     uint64_t slot_entries;        /* entries put into slot_of (stale ones stay until the next rebuild) */
     uint64_t patches, last_patch_tables;
+    Map table_batch;              /* table pointer -> its live batch (rebuilt with the slots, kept up to date by patch()) */
+    uint64_t table_batch_entries;
+    uint8_t* slot_has_kids;       /* per slot: some batch names it as its parent slot (set, never cleared between rebuilds) */
 
     int status;
     uint64_t rebuilds;
@@ -892,6 +895,8 @@ void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     free(s->batches);
     free(s->walk_entities);
     free(s->mesh_dirty);
+    map_free(&s->table_batch);
+    free(s->slot_has_kids);
     free(s->cached_entities);
     free(s->cached_src);
     free(s->cached_counts);
