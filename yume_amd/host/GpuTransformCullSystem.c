@@ -188,6 +188,7 @@ struct GpuTransformCullSystem {
     uint64_t patches, last_patch_tables;
     Map table_batch;              /* table pointer -> its live batch (rebuilt with the slots, kept up to date by patch()) */
     uint64_t table_batch_entries;
+    int patch_index_valid;        /* table_batch / slot_has_kids describe the batches (rebuild() clears it) */
     uint8_t* slot_has_kids;       /* per slot: some batch names it as its parent slot (set, never cleared between rebuilds) */
 
     int status;
