@@ -115,6 +115,11 @@ struct GpuTransformCullSystem {
     uint64_t n_mesh_dirty, cap_mesh_dirty;
 
     float planes[YH_MAX_FRUSTA * 24];
+    float frame_planes[YH_MAX_FRUSTA * 24]; /* the inputs of the last frame that ran on the device (idle frames: run()) */
+    uint32_t frame_n_frusta;
+    uint8_t frame_root[64];
+    int frame_has_root, frame_valid, idle_skip;
+    uint64_t frames_idle;
     uint32_t n_frusta;
     uint32_t n_explicit;                      /* frusta handed over with setFrusta: they override the cameras */
     /* inputs read from the ECS (optional): Camera.view_projection and the AABB of the mesh an entity's Mesh refers to */
@@ -374,6 +379,7 @@ static void run(ecs_iter_t* it) {
         s->root = root;
         s->batches_live = 1;
     }
+    const int inputs_changed = s->bounds_stale || s->n_mesh_dirty; /* boxes or keys go up below */
     if (s->bounds_stale) s->n_mesh_dirty = 0; /* (every id is read afresh) */
     if ((s->bounds_stale && (rc = upload_bounds(s)) != YH_OK) || (s->n_mesh_dirty && (rc = mesh_ids_refresh(s)) != YH_OK)) {
         s->status = rc;
@@ -450,6 +456,24 @@ static void run(ecs_iter_t* it) {
     }
     const uint32_t cull_flags = s->n_frusta ? 0u : YH_FRAME_NO_CULL;
     const double t_up = now_ms();
+    /* A frame that has nothing to do: no structural change, no row set since the last frame, the root's row clean and the
+     * same, the same bounds and the same frusta as the frame before.  The device would recompute nothing and list the same
+     * entities: no launch, no copy - the lists and rows of the last frame stand.  (The reference's CPU systems visit every
+     * row every frame to find the same out: TransformSyncSystem.zig:60.) */
+    if (s->idle_skip && s->incremental && clean && !rebuilt && !inputs_changed && s->last_up_rows == 0 && s->last_patch_tables == 0 &&
+        s->frame_valid &&
+        !(s->readback && s->host_stale) && s->n_frusta == s->frame_n_frusta &&
+        memcmp(s->planes, s->frame_planes, sizeof(float) * 24 * s->n_frusta) == 0 &&
+        (root_row ? (s->frame_has_root && root_row[64] == 0 && memcmp(root_row, s->frame_root, 64) == 0) : !s->frame_has_root)) {
+        s->n_dirty[0] = s->n_dirty[1] = 0;
+        s->last_down_rows = 0;
+        s->frames_idle += 1;
+        s->last_ms[0] = t_inputs - t_begin;
+        s->last_ms[1] = t_up - t_inputs;
+        s->status = YH_OK;
+        return;
+    }
+    s->frame_valid = 0;
     rc = yh_frame(s->scene, s->planes, s->n_frusta, cull_flags); /* returns when the device is done */
     const double t_frame = now_ms();
     if (rc != YH_OK) {
@@ -493,6 +517,11 @@ static void run(ecs_iter_t* it) {
     }
     s->n_dirty[0] = s->n_dirty[1] = 0;
     if (root_row) root_row[64] = 0; /* PostWorldTransform reaches the root too (single-term query) */
+    s->frame_n_frusta = s->n_frusta; /* what this frame was computed from: the next one may find it has nothing to do */
+    memcpy(s->frame_planes, s->planes, sizeof s->frame_planes);
+    s->frame_has_root = root_row != NULL;
+    if (root_row) memcpy(s->frame_root, root_row, 64);
+    s->frame_valid = 1;
     s->last_ms[0] = t_inputs - t_begin;
     s->last_ms[1] = t_up - t_inputs;
     s->last_ms[2] = t_frame - t_up;
@@ -541,6 +570,7 @@ ecs_entity_t GpuTransformCullSystem_registerTo(ecs_world_t* world, ecs_entity_t 
     s->structure_dirty = 1;
     s->readback = 1;
     s->patching = 1;
+    s->idle_skip = getenv("YUME_GPU_SYSTEM_NO_IDLE_SKIP") == NULL; /* (the knob: A/B) */
     s->refresh = getenv("YUME_GPU_SYSTEM_NO_REFRESH") == NULL; /* (the knob: A/B and the tests that compare both ways) */
     {
         long cpus = sysconf(_SC_NPROCESSORS_ONLN);
@@ -873,6 +903,7 @@ int GpuTransformCullSystem_structureDirty(const GpuTransformCullSystem* s) { ret
 void GpuTransformCullSystem_clearStructureDirty(GpuTransformCullSystem* s) {
     if (s) s->structure_dirty = 0;
 }
+uint64_t GpuTransformCullSystem_idleFrames(const GpuTransformCullSystem* s) { return s ? s->frames_idle : 0; }
 uint64_t GpuTransformCullSystem_cleanFrames(const GpuTransformCullSystem* s) { return s ? s->frames_clean : 0; }
 
 void GpuTransformCullSystem_walkStats(const GpuTransformCullSystem* s, uint64_t* walks, uint64_t* skipped) {

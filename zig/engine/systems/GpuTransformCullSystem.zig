@@ -56,6 +56,7 @@ extern fn GpuTransformCullSystem_setReadback(s: *State, on: c_int) c_int;
 extern fn GpuTransformCullSystem_fetchWorld(s: *State, entity: c.ecs_entity_t, matrix: *[16]f32) c_int;
 extern fn GpuTransformCullSystem_setThreads(s: *State, n: c_int) c_int;
 extern fn GpuTransformCullSystem_cleanFrames(s: *const State) u64;
+extern fn GpuTransformCullSystem_idleFrames(s: *const State) u64;
 extern fn GpuTransformCullSystem_walkStats(s: *const State, walks: ?*u64, skipped: ?*u64) void;
 extern fn GpuTransformCullSystem_lastTimes(s: *const State, ms: *[6]f64) void;
 extern fn GpuTransformCullSystem_lastTraffic(s: *const State, rows_up: ?*u64, rows_down: ?*u64) void;
@@ -211,6 +212,11 @@ pub fn patches() u64 {
 }
 pub fn setPatching(on: bool) void {
     _ = GpuTransformCullSystem_setPatching(state.?, @intFromBool(on));
+}
+/// Frames that had nothing to do (no structural change, no row set, the same root, bounds and frusta as the frame before)
+/// and launched nothing: the last frame's rows and lists stand.
+pub fn idleFrames() u64 {
+    return if (state) |s| GpuTransformCullSystem_idleFrames(s) else 0;
 }
 
 /// Status of the last frame (system callbacks cannot return one), or of the last call above that failed.
