@@ -1105,3 +1105,51 @@ def test_a_patch_of_hundreds_of_tables_goes_up_in_one_call_per_array(oracle, tmp
         for f in range(cull_planes.shape[0]):
             assert np.array_equal(np.sort(vis[f]), here[np.flatnonzero(exp_vis[f])]), f"frame {fi} frustum {f}: visible set {stats}"
     assert gpu[-1][2] == 1 and gpu[-1][4][-1][4] == 3, f"three patched frames, no rebuild: {gpu[-1][4][-1]}, rebuilds {gpu[-1][2]}"
+
+
+@pytest.mark.gpu
+def test_frames_with_nothing_to_do_launch_nothing_and_change_nothing(oracle, tmp_path):
+    """Idle frames: no structural change, no row set, the same root, bounds and frusta as the frame before - the system
+    launches nothing and the last frame's rows and lists stand.  The run's output must be byte for byte what the same run
+    produces with the shortcut switched off (YUME_GPU_SYSTEM_NO_IDLE_SKIP), and exactly the frames without edits that
+    follow a frame of the same kind count as idle: not the first frame, not a frame with an edit, a deletion or a moved
+    root, not the frame after a structural change's patch either way."""
+    n, levels = 20_000, 5
+    rng = np.random.default_rng(9)
+    lo = oracle.synth_level_offsets(n, levels)
+    par = oracle.synth_parents(lo)
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo[1])))
+    bounds = oracle.synth_aabb(n)
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    m = oracle.compose([1, 2, 3], [0, 0, 0, 1], [1, 1, 1])
+    leaf = n - 1
+    frames = [[], [], [(17, 0, m)], [], [], [(-1, 1, oracle.compose([1, 2, 3], [0, 0.7071068, 0, 0.7071068], [2, 2, 2]))], [],
+              [(leaf, 2, np.zeros(16, np.float32))], [], [(int(lo[2]) + 3, 1, m)], []]
+    idle_expected = [0, 1, 1, 2, 3, 3, 4, 4, 5, 5, 6]  # running count after every frame
+    scene = tmp_path / "scene.bin"
+    write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
+    outs = {}
+    for skip in (True, False):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
+        env["YFH_TIMES"] = "1"
+        env.pop("YUME_GPU_SYSTEM_NO_IDLE_SKIP", None)
+        if not skip:
+            env["YUME_GPU_SYSTEM_NO_IDLE_SKIP"] = "1"
+        out = tmp_path / f"gpu_{int(skip)}.bin"
+        r = subprocess.run([GPU, str(scene), str(out)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        idle = [int(line.rsplit(" ", 1)[1]) for line in r.stderr.splitlines() if line.startswith("stages ")]
+        assert idle == (idle_expected if skip else [0] * len(frames)), f"idle frames {idle}"
+        outs[skip] = open(out, "rb").read()
+    # (the traffic counters at the end of every frame's record are equal too: an idle frame moves no rows either way)
+    assert outs[True] == outs[False], "the shortcut changed what the frames produce"
+    out_c = tmp_path / "cpu.bin"
+    subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
+    cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
+    gpu = read_out(tmp_path / "gpu_1.bin", n, len(frames), 1, oracle.T68, gpu=True)
+    for fi, ((cw, cl, _, _rows, _), (gw, gl, _r, _g, vis)) in enumerate(zip(cpu, gpu)):
+        with np.errstate(all="ignore"):
+            assert np.array_equal(gw["m"], cw["m"], equal_nan=True) and np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi}"
+        here = np.flatnonzero(cw["m"].any(axis=1) | cl["m"].any(axis=1))
+        exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[here]), np.ascontiguousarray(bounds[here]), planes)
+        assert np.array_equal(np.sort(vis[0]), here[np.flatnonzero(exp_vis[0])]), f"frame {fi}: visible set"
