@@ -92,6 +92,11 @@ typedef struct yh_scene_desc {
                                      reads them (counts, a list, a consumer, yh_wait) before the next frame starts; the
                                      next frame otherwise drops them unexpanded.  For frames whose visibility words go
                                      to yh_allgather_draw_lists_async, whose gathered lists already hold this GPU's part */
+#define YH_FRAME_CULL_ONLY 0x20u /* nothing moved since the last frame - no row uploaded or marked dirty, the root's row
+                                     clean and unchanged (the caller vouches for it; a dirty root is refused) - only the
+                                     frusta (or the bounds) changed: one launch culls the world matrices the last frame
+                                     left, no rule, no sweep; with change tracking on the frame reports no changed row.
+                                     The common frame of an editor or a game: a camera moved (GameWindow.zig:154-178)   */
 
 typedef struct yh_timing {
     float last_frame_ms;    /* device time of the most recent frame (hipEvent; 0 unless kernel timing is on) */

@@ -447,8 +447,9 @@ int main(int argc, char** argv) {
 #ifdef USE_GPU_SYSTEM
             double st[6];
             GpuTransformCullSystem_lastTimes(gpu, st);
-            fprintf(stderr, "stages %u: inputs %.3f (walk %.3f, rebuild %.3f) up %.3f frame %.3f down %.3f; idle frames so far %llu\n", f, st[0], st[4], st[5],
-                    st[1], st[2], st[3], (unsigned long long)GpuTransformCullSystem_idleFrames(gpu));
+            fprintf(stderr, "stages %u: inputs %.3f (walk %.3f, rebuild %.3f) up %.3f frame %.3f down %.3f; cull-only frames so far %llu; idle frames so far %llu\n", f, st[0],
+                    st[4], st[5], st[1], st[2], st[3], (unsigned long long)GpuTransformCullSystem_cullOnlyFrames(gpu),
+                    (unsigned long long)GpuTransformCullSystem_idleFrames(gpu));
 #endif
         }
         for (int comp = 0; comp < 2; ++comp) {

@@ -687,3 +687,107 @@ def test_rows_change_slots_on_the_device(ctx, oracle):
         with pytest.raises(_lib.YumeHipError) as e:
             t.move_rows(np.array([1], np.uint32), np.array([2], np.uint32))
         assert e.value.code == _lib.YH_ERR_STATE
+
+
+@pytest.mark.parametrize("kind", ["mat4", "mat4-mesh-table", "trs"])
+def test_cull_only_frames_equal_a_full_frame_with_the_same_frusta(ctx, oracle, kind):
+    """YH_FRAME_CULL_ONLY (only a camera or the bounds changed): one launch culls the world matrices the device holds.
+    Its lists, counts and boundary counts equal the oracle's cull of the same rows and a full frame's with the same
+    frusta; the world rows and flags stay as they were; the changed lists are empty; dead slots stay out of the lists;
+    and it is refused before the first frame, with a dirty root's row and together with YH_FRAME_ALL_DIRTY."""
+    from yume_amd import Scene, _lib
+
+    n = 300_001  # a last chunk of one entity
+    lo, par, bounds, local, world = build(oracle, n, 7, seed=oracle.SEED + 3)
+    root = oracle.identity68()
+    cams = np.concatenate([oracle.main_camera_planes().reshape(1, 24), oracle.cascade_planes()[:3]])
+    mesh = kind == "mat4-mesh-table"
+    if mesh:
+        rng = np.random.default_rng(5)
+        table = np.concatenate([rng.uniform(-3, 0, (32, 3)), rng.uniform(0, 3, (32, 3))], axis=1).astype(np.float32)
+        ids = rng.integers(0, 32, n).astype(np.uint32)
+        bounds = table[ids]
+    kw = dict(n_levels=7, n_frusta=4)
+    if kind != "trs":
+        kw["local_kind"] = _lib.YH_LOCAL_MAT4
+    if mesh:
+        kw.update(bounds_kind=_lib.YH_BOUNDS_MESH_TABLE, max_meshes=32)
+    with Scene(ctx, n, **kw) as s:
+        s.upload_hierarchy(par, lo)
+        if mesh:
+            s.upload_mesh_aabbs(table)
+            s.upload_mesh_ids(ids)
+        else:
+            s.upload_aabb(np.ascontiguousarray(bounds[:, 0:3].T), np.ascontiguousarray(bounds[:, 3:6].T))
+        if kind == "trs":
+            trs = oracle.synth_trs(n, int(lo[1]))
+            s.upload_trs(trs)
+            exp_w = oracle.frame_trs(trs, par, lo, n_threads=8)
+            full = _lib.YH_FRAME_ALL_DIRTY
+        else:
+            s.upload_local_aos68(local)
+            s.upload_world_aos68(world)
+            s.upload_root_aos68(root)
+            s.track_changes(True)
+            oracle.frame_aos68(world, local, par, lo, root)
+            exp_w = world
+            full = 0
+        with pytest.raises(_lib.YumeHipError) as e:  # no world matrices yet
+            s.frame(cams[:1], _lib.YH_FRAME_CULL_ONLY)
+        assert e.value.code == _lib.YH_ERR_STATE
+        s.frame(cams[:1], full)
+        before = s.world_soa().copy()
+
+        def check(nf, planes, tag, dead=None):
+            vis, bnd = oracle.cull(exp_w, bounds, planes, n_threads=8)
+            if dead is not None:
+                vis[:, dead] = 0
+                bnd[:, dead] = 0
+            counts, bcounts = s.counts()
+            for f in range(nf):
+                assert counts[f] == np.count_nonzero(vis[f]) and bcounts[f] == np.count_nonzero(bnd[f]), (tag, f)
+                assert np.array_equal(s.draw_list(f), np.flatnonzero(vis[f]).astype(np.uint32)), (tag, f)
+
+        for rnd, sel in enumerate([[1, 2, 3], [0], [3, 1], [0, 1, 2, 3], [2]]):
+            planes = cams[sel]
+            fl = _lib.YH_FRAME_CULL_ONLY | (_lib.YH_FRAME_ASYNC if rnd % 2 else 0)
+            s.frame(planes, fl)
+            assert "k_cull_only" in s.group_kernel_names()[0]
+            check(len(sel), planes, f"cull-only {rnd}")
+            if kind != "trs":
+                assert s.changed_counts() == (0, 0)
+        assert np.array_equal(s.world_soa().view(np.uint32), before.view(np.uint32))
+        # a full frame with the same frusta gives the same lists (nothing is dirty: the Mat4 rule leaves every row alone)
+        planes = cams[[2, 0]]
+        s.frame(planes, _lib.YH_FRAME_CULL_ONLY)
+        a = [s.draw_list(f).copy() for f in range(2)]
+        s.frame(planes, full)
+        assert all(np.array_equal(a[f], s.draw_list(f)) for f in range(2))
+        if kind != "trs":
+            # bounds edited (MeshComponent set / asset loaded), nothing moved: cull-only sees the new boxes
+            sl = np.arange(10, n, 977, dtype=np.uint32)
+            if mesh:
+                ids[sl] = (ids[sl] + 7) % 32
+                s.upload_mesh_id_rows(sl, ids[sl])
+                bounds = table[ids]
+            else:
+                bounds = bounds.copy()
+                bounds[sl, 3:6] += 40.0
+                s.upload_aabb_rows(sl, bounds[sl])
+            s.frame(cams[:2], _lib.YH_FRAME_CULL_ONLY)
+            check(2, cams[:2], "after a bounds edit")
+            # dead slots (entities deleted since) are in no list
+            s.set_alive_range(1000, 5000, False)
+            s.frame(cams[:2], _lib.YH_FRAME_CULL_ONLY)
+            check(2, cams[:2], "dead slots", dead=slice(1000, 6000))
+            # a dirty root row moves every matrix: refused, the caller has to run the rule
+            dirty_root = root.copy()
+            dirty_root["dirty"] = 1
+            s.upload_root_aos68(dirty_root)
+            with pytest.raises(_lib.YumeHipError) as e:
+                s.frame(cams[:2], _lib.YH_FRAME_CULL_ONLY)
+            assert e.value.code == _lib.YH_ERR_STATE
+            s.frame(cams[:2], 0)
+        with pytest.raises(_lib.YumeHipError) as e:
+            s.frame(cams[:2], _lib.YH_FRAME_CULL_ONLY | _lib.YH_FRAME_ALL_DIRTY)
+        assert e.value.code == _lib.YH_ERR_BAD_ARG

@@ -1153,3 +1153,69 @@ def test_frames_with_nothing_to_do_launch_nothing_and_change_nothing(oracle, tmp
         here = np.flatnonzero(cw["m"].any(axis=1) | cl["m"].any(axis=1))
         exp_vis, _ = oracle.cull(np.ascontiguousarray(cw[here]), np.ascontiguousarray(bounds[here]), planes)
         assert np.array_equal(np.sort(vis[0]), here[np.flatnonzero(exp_vis[0])]), f"frame {fi}: visible set"
+
+
+@pytest.mark.gpu
+def test_frames_in_which_only_a_camera_or_a_mesh_changed_cull_without_running_the_rule(oracle, tmp_path):
+    """The common frame: nothing moved, a camera did (or a MeshComponent was set on an entity that has one).  The system
+    passes YH_FRAME_CULL_ONLY: one launch culls the world matrices the device holds.  Exactly those frames count, the run's
+    output is byte for byte what it is with the shortcuts switched off (every frame runs the rule), and the visible sets
+    are the oracle's for each frame's cameras and meshes."""
+    from yume_amd import api, synth
+
+    n, levels = 30_000, 6
+    rng = np.random.default_rng(21)
+    lo = oracle.synth_level_offsets(n, levels)
+    par = oracle.synth_parents(lo)
+    local = oracle.compose_batch(oracle.synth_trs(n, int(lo[1])))
+    mesh_box = {0: [0, 0, 0, 0, 0, 0]}
+    for k in (1, 2, 3):
+        mesh_box[k] = [-0.5 * k, -0.25 * k - 0.5, -1.0, 0.5 * k, 0.25 * k + 0.5, 1.5]
+    mesh_of = (np.arange(n) % 4).astype(np.int64)
+    cam = [synth.main_camera_planes(), synth.cascade_planes()[1]]
+
+    def arg_u32(v):
+        m = np.zeros(16, np.float32)
+        m.view(np.uint32)[0] = v
+        return m
+
+    def vp(k):
+        return api.mat4_mul(api.perspective(np.radians(70.0), 1.6, 0.1, 250.0), api.look_at([3.0 * k, 30.0, 120.0 - 5 * k], [0, 0, 0], [0, 1, 0]))
+
+    remesh = np.unique(rng.integers(0, n, 400))
+    remesh = remesh[mesh_of[remesh] != 0][:200]
+    m = oracle.compose([1, 2, 3], [0, 0, 0, 1], [1, 1, 1])
+    frames = [[], [(0, 5, vp(1))], [(0, 5, vp(2)), (1, 5, vp(7))], [], [(int(lo[3]) + 5, 0, m)], [(0, 5, vp(3))],
+              [(int(e), 4, arg_u32(int(mesh_of[e]) % 3 + 1)) for e in remesh], [(0, 5, vp(4)), (77, 1, m)], [(1, 5, vp(5))], []]
+    cull_only_expected = [0, 1, 2, 2, 2, 3, 4, 4, 5, 5]  # running count after every frame
+    scene, out_c = tmp_path / "scene.bin", tmp_path / "cpu.bin"
+    write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], np.zeros((1, 24), np.float32), np.zeros((n, 6), np.float32), frames)
+    outs = {}
+    for shortcut in (True, False):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("YFH_")}
+        env.update(YFH_TIMES="1", YFH_ECS_INPUTS="1")
+        env.pop("YUME_GPU_SYSTEM_NO_IDLE_SKIP", None)
+        if not shortcut:
+            env["YUME_GPU_SYSTEM_NO_IDLE_SKIP"] = "1"
+        out = tmp_path / f"gpu_{int(shortcut)}.bin"
+        r = subprocess.run([GPU, str(scene), str(out)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = [int(line.split("cull-only frames so far ")[1].split(";")[0]) for line in r.stderr.splitlines() if line.startswith("stages ")]
+        assert got == (cull_only_expected if shortcut else [0] * len(frames)), f"cull-only frames {got}"
+        outs[shortcut] = open(out, "rb").read()
+    assert outs[True] == outs[False], "cull-only frames changed what the frames produce"
+    subprocess.check_call([CPU, str(scene), str(out_c)], timeout=300)
+    cpu = read_out(out_c, n, len(frames), 0, oracle.T68)
+    gpu = read_out(tmp_path / "gpu_1.bin", n, len(frames), 2, oracle.T68, gpu=True)
+    for fi, ((cw, cl, _, _rows, _), (gw, gl, _rb, _g_rows, vis)) in enumerate(zip(cpu, gpu)):
+        for e, kind, mm in frames[fi]:
+            if kind == 4:
+                mesh_of[e] = int(mm.view(np.uint32)[0])
+            if kind == 5:
+                cam[e] = api.extract_planes(mm)
+        with np.errstate(all="ignore"):
+            assert np.array_equal(gw["m"], cw["m"], equal_nan=True) and np.array_equal(gl["m"], cl["m"], equal_nan=True), f"frame {fi}"
+        bounds = np.array([mesh_box[int(k)] for k in mesh_of], np.float32)
+        exp_vis, _ = oracle.cull(np.ascontiguousarray(cw), bounds, np.stack(cam).astype(np.float32).reshape(2, 24))
+        for f in range(2):
+            assert np.array_equal(np.sort(vis[f]), np.flatnonzero(exp_vis[f])), f"frame {fi} frustum {f}: visible set"

@@ -33,6 +33,7 @@ YH_FRAME_NO_CULL = 0x2
 YH_FRAME_ASYNC = 0x4
 YH_FRAME_ORDERED = 0x8
 YH_FRAME_LISTS_ON_DEMAND = 0x10
+YH_FRAME_CULL_ONLY = 0x20
 
 
 class SceneDesc(C.Structure):

@@ -249,7 +249,15 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
         if (s->desc.bounds_kind == YH_BOUNDS_MESH_TABLE && s->n_meshes == 0)
             return fail(ctx, YH_ERR_STATE, "%s: mesh table not uploaded", who);
     }
-    if (s->desc.local_kind == YH_LOCAL_TRS && !(flags & YH_FRAME_ALL_DIRTY))
+    const bool cull_only = (flags & YH_FRAME_CULL_ONLY) != 0;
+    if (cull_only) {
+        if (use_static) return fail(ctx, YH_ERR_UNSUPPORTED, "%s: YH_FRAME_CULL_ONLY is a yh_frame flag", who);
+        if (flags & (YH_FRAME_ALL_DIRTY | YH_FRAME_LISTS_ON_DEMAND))
+            return fail(ctx, YH_ERR_BAD_ARG, "%s: YH_FRAME_CULL_ONLY goes with neither YH_FRAME_ALL_DIRTY nor YH_FRAME_LISTS_ON_DEMAND", who);
+        if (s->frames == 0) return fail(ctx, YH_ERR_STATE, "%s: YH_FRAME_CULL_ONLY needs the world matrices of an earlier frame", who);
+        if (s->root_dirty) return fail(ctx, YH_ERR_STATE, "%s: YH_FRAME_CULL_ONLY with a dirty root row: every row below it has to be recomputed", who);
+    }
+    if (s->desc.local_kind == YH_LOCAL_TRS && !(flags & YH_FRAME_ALL_DIRTY) && !cull_only)
         return fail(ctx, YH_ERR_UNSUPPORTED, "%s: TRS scenes recompute every entity; pass YH_FRAME_ALL_DIRTY", who);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -381,7 +389,24 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
 
     s->group_kernel.assign(s->groups.size(), std::string());
     std::string kn;
-    if (s->desc.local_kind == YH_LOCAL_TRS) {
+    if (cull_only) {
+        if (s->exp_pending)  // an expansion a deferred frame left behind: no first launch of a rule here to carry it
+            if (int rc = flush_expand(s)) return rc;
+        if (cull) {  // (without frusta there is nothing to do at all)
+            a.begin = 0;
+            a.end = (uint32_t)s->n;
+            const dim3 grid((uint32_t)cdiv(s->n, YH_BLOCK));
+            if (bounds == 1) hipLaunchKernelGGL((k_cull_only<1>), grid, dim3(YH_BLOCK), 0, st, a);
+            else hipLaunchKernelGGL((k_cull_only<2>), grid, dim3(YH_BLOCK), 0, st, a);
+            HIP_TRY(ctx, hipGetLastError());
+            if (!s->group_kernel.empty()) s->group_kernel[0] = bounds == 1 ? "k_cull_only<1>" : "k_cull_only<2>";
+            ++launches;
+        }
+        if (s->track) {  // no row changed: both change lists are empty
+            HIP_TRY(ctx, hipMemsetAsync(s->h_chg_dev, 0, 2 * sizeof(uint32_t), st));
+            s->chg_valid = true;
+        }
+    } else if (s->desc.local_kind == YH_LOCAL_TRS) {
         if (s->exp_pending && (s->groups.empty() || s->groups[0].lo != 0 || s->level_offsets[s->groups[0].hi + 1] == s->level_offsets[0]))
             if (int rc = flush_expand(s)) return rc;
         for (uint32_t gi = 0; gi < s->groups.size(); ++gi) {

@@ -600,6 +600,27 @@ __global__ __launch_bounds__(YH_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) v
     if (tile < a.n_tiles) frame_chain_tile<G, BOUNDS, false>(a, tile);
 }
 
+// YH_FRAME_CULL_ONLY: the world matrices of the last frame against this frame's frusta, every slot of the scene in one
+// launch (no hierarchy: a row is a row).
+template <int BOUNDS>
+__global__ __launch_bounds__(YH_BLOCK) void k_cull_only(const FrameArgs a) {
+    const uint32_t tid = threadIdx.x;
+    const uint64_t e64 = (uint64_t)blockIdx.x * YH_BLOCK + tid;
+    if (e64 - (tid & 63u) >= a.end) return;  // wave-uniform
+    const bool valid = e64 < a.end;
+    const uint32_t e = valid ? (uint32_t)e64 : a.end - 1u;
+    float b[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t mesh = 0;
+    if (BOUNDS == 1) load_row<6>(a.bounds, e, b);
+    else mesh = a.mesh_id[e];
+    M4 w;
+    load_row<16>(a.world, e, w.v);
+    uint32_t vmask = 0, bmask = 0;
+    cull_entity<BOUNDS>(a, w, b, mesh, vmask, bmask);
+    if (!valid) vmask = bmask = 0;
+    publish_visible(a, (uint32_t)(e64 >> 6), false, vmask, bmask);
+}
+
 // WorldTransform.dirty on the device is "non-zero".  A row that took the reverse branch (its LOCAL matrix was re-derived,
 // TransformSyncSystem.zig:69-72) carries this value instead of 1 until the frame's sweep, which files it under the rows
 // whose LocalTransform has to go back to the host; every other reader tests != 0 only.  (Uploads normalise to 0 / 1.)

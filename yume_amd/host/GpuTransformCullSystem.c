@@ -119,7 +119,7 @@ struct GpuTransformCullSystem {
     uint32_t frame_n_frusta;
     uint8_t frame_root[64];
     int frame_has_root, frame_valid, idle_skip;
-    uint64_t frames_idle;
+    uint64_t frames_idle, frames_cull_only;
     uint32_t n_frusta;
     uint32_t n_explicit;                      /* frusta handed over with setFrusta: they override the cameras */
     /* inputs read from the ECS (optional): Camera.view_projection and the AABB of the mesh an entity's Mesh refers to */
@@ -460,11 +460,12 @@ static void run(ecs_iter_t* it) {
      * same, the same bounds and the same frusta as the frame before.  The device would recompute nothing and list the same
      * entities: no launch, no copy - the lists and rows of the last frame stand.  (The reference's CPU systems visit every
      * row every frame to find the same out: TransformSyncSystem.zig:60.) */
-    if (s->idle_skip && s->incremental && clean && !rebuilt && !inputs_changed && s->last_up_rows == 0 && s->last_patch_tables == 0 &&
-        s->frame_valid &&
-        !(s->readback && s->host_stale) && s->n_frusta == s->frame_n_frusta &&
-        memcmp(s->planes, s->frame_planes, sizeof(float) * 24 * s->n_frusta) == 0 &&
-        (root_row ? (s->frame_has_root && root_row[64] == 0 && memcmp(root_row, s->frame_root, 64) == 0) : !s->frame_has_root)) {
+    /* nothing moved: no structural change, no row set since the last frame, the root's row clean and the same */
+    const int nothing_moved = s->idle_skip && s->incremental && clean && !rebuilt && s->last_up_rows == 0 && s->last_patch_tables == 0 &&
+                              s->frame_valid && !(s->readback && s->host_stale) &&
+                              (root_row ? (s->frame_has_root && root_row[64] == 0 && memcmp(root_row, s->frame_root, 64) == 0) : !s->frame_has_root);
+    if (nothing_moved && !inputs_changed && s->n_frusta == s->frame_n_frusta &&
+        memcmp(s->planes, s->frame_planes, sizeof(float) * 24 * s->n_frusta) == 0) {
         s->n_dirty[0] = s->n_dirty[1] = 0;
         s->last_down_rows = 0;
         s->frames_idle += 1;
@@ -474,7 +475,11 @@ static void run(ecs_iter_t* it) {
         return;
     }
     s->frame_valid = 0;
-    rc = yh_frame(s->scene, s->planes, s->n_frusta, cull_flags); /* returns when the device is done */
+    /* Only the frusta (a camera moved: the common frame) or the bounds changed: the device culls the world matrices it
+     * holds, in one launch - no rule, no sweep, no changed rows. */
+    const uint32_t only_cull = nothing_moved && s->n_frusta ? YH_FRAME_CULL_ONLY : 0u;
+    s->frames_cull_only += only_cull != 0;
+    rc = yh_frame(s->scene, s->planes, s->n_frusta, cull_flags | only_cull); /* returns when the device is done */
     const double t_frame = now_ms();
     if (rc != YH_OK) {
         s->n_dirty[0] = s->n_dirty[1] = 0;
@@ -904,6 +909,7 @@ void GpuTransformCullSystem_clearStructureDirty(GpuTransformCullSystem* s) {
     if (s) s->structure_dirty = 0;
 }
 uint64_t GpuTransformCullSystem_idleFrames(const GpuTransformCullSystem* s) { return s ? s->frames_idle : 0; }
+uint64_t GpuTransformCullSystem_cullOnlyFrames(const GpuTransformCullSystem* s) { return s ? s->frames_cull_only : 0; }
 uint64_t GpuTransformCullSystem_cleanFrames(const GpuTransformCullSystem* s) { return s ? s->frames_clean : 0; }
 
 void GpuTransformCullSystem_walkStats(const GpuTransformCullSystem* s, uint64_t* walks, uint64_t* skipped) {

@@ -154,6 +154,9 @@ uint64_t GpuTransformCullSystem_cleanFrames(const GpuTransformCullSystem* s);
 /* Frames that had nothing to do at all - no structural change, no row set, the same root, bounds and frusta as the frame
  * before - and so launched nothing: the last frame's rows and lists stand (incremental mode). */
 uint64_t GpuTransformCullSystem_idleFrames(const GpuTransformCullSystem* s);
+/* Frames in which nothing moved but the frusta or the bounds changed (a camera moved): one launch culled the world
+ * matrices the device holds (YH_FRAME_CULL_ONLY). */
+uint64_t GpuTransformCullSystem_cullOnlyFrames(const GpuTransformCullSystem* s);
 /* Readback (on by default): the rows a frame recomputed come back into the flecs columns, so every CPU reader of
  * WorldTransform.matrix keeps working (RenderApi.zig:1398-1402, SceneWindow.zig:334-351).  Off, for a renderer that
  * takes matrices and draw records on the device (yh_build_object_data / yh_object_data_device): nothing comes back, a

@@ -57,6 +57,7 @@ extern fn GpuTransformCullSystem_fetchWorld(s: *State, entity: c.ecs_entity_t, m
 extern fn GpuTransformCullSystem_setThreads(s: *State, n: c_int) c_int;
 extern fn GpuTransformCullSystem_cleanFrames(s: *const State) u64;
 extern fn GpuTransformCullSystem_idleFrames(s: *const State) u64;
+extern fn GpuTransformCullSystem_cullOnlyFrames(s: *const State) u64;
 extern fn GpuTransformCullSystem_walkStats(s: *const State, walks: ?*u64, skipped: ?*u64) void;
 extern fn GpuTransformCullSystem_lastTimes(s: *const State, ms: *[6]f64) void;
 extern fn GpuTransformCullSystem_lastTraffic(s: *const State, rows_up: ?*u64, rows_down: ?*u64) void;
@@ -217,6 +218,10 @@ pub fn setPatching(on: bool) void {
 /// and launched nothing: the last frame's rows and lists stand.
 pub fn idleFrames() u64 {
     return if (state) |s| GpuTransformCullSystem_idleFrames(s) else 0;
+}
+/// Frames in which only the frusta or the bounds changed: one launch culled the matrices the device holds.
+pub fn cullOnlyFrames() u64 {
+    return if (state) |s| GpuTransformCullSystem_cullOnlyFrames(s) else 0;
 }
 
 /// Status of the last frame (system callbacks cannot return one), or of the last call above that failed.
