@@ -92,11 +92,14 @@ typedef struct yh_scene_desc {
                                      reads them (counts, a list, a consumer, yh_wait) before the next frame starts; the
                                      next frame otherwise drops them unexpanded.  For frames whose visibility words go
                                      to yh_allgather_draw_lists_async, whose gathered lists already hold this GPU's part */
-#define YH_FRAME_CULL_ONLY 0x20u /* nothing moved since the last frame - no row uploaded or marked dirty, the root's row
-                                     clean and unchanged (the caller vouches for it; a dirty root is refused) - only the
-                                     frusta (or the bounds) changed: one launch culls the world matrices the last frame
-                                     left, no rule, no sweep; with change tracking on the frame reports no changed row.
-                                     The common frame of an editor or a game: a camera moved (GameWindow.zig:154-178)   */
+#define YH_FRAME_CULL_ONLY 0x20u /* cull what the device holds: one launch tests the world matrices the last frame left
+                                     (and the bounds as they are now) against these frusta and writes the lists; no
+                                     rule, no sweep.  For frames in which nothing moved but a camera did (GameWindow.zig:
+                                     154-178) or a mesh changed, and for further frusta over the same frame's matrices.
+                                     Rows uploaded or marked dirty since the last frame, a dirty root row included, stay
+                                     pending for the next full frame; with change tracking on this frame reports no changed row.  Not
+                                     before the first frame (YH_ERR_STATE), not with YH_FRAME_ALL_DIRTY /
+                                     _LISTS_ON_DEMAND (YH_ERR_BAD_ARG), not in yh_frame_static (YH_ERR_UNSUPPORTED) */
 
 typedef struct yh_timing {
     float last_frame_ms;    /* device time of the most recent frame (hipEvent; 0 unless kernel timing is on) */

@@ -780,14 +780,25 @@ def test_cull_only_frames_equal_a_full_frame_with_the_same_frusta(ctx, oracle, k
             s.set_alive_range(1000, 5000, False)
             s.frame(cams[:2], _lib.YH_FRAME_CULL_ONLY)
             check(2, cams[:2], "dead slots", dead=slice(1000, 6000))
-            # a dirty root row moves every matrix: refused, the caller has to run the rule
-            dirty_root = root.copy()
-            dirty_root["dirty"] = 1
-            s.upload_root_aos68(dirty_root)
-            with pytest.raises(_lib.YumeHipError) as e:
-                s.frame(cams[:2], _lib.YH_FRAME_CULL_ONLY)
-            assert e.value.code == _lib.YH_ERR_STATE
+            # what is pending stays pending: a moved root and an edited row wait for the next full frame, which then
+            # gives what the oracle gives
+            s.set_alive_range(1000, 5000, True)
+            root["m"][0] = oracle.compose([3, -2, 5], [0, 0.38268343, 0, 0.92387953], [1, 1, 1])
+            root["dirty"] = 1
+            s.upload_root_aos68(root)
+            edit = np.array([int(lo[2]) + 11], np.uint32)
+            local["m"][edit] = oracle.compose([9, 9, 9], [0, 0, 0, 1], [2, 2, 2])
+            local["dirty"][edit] = 1
+            s.upload_local_rows(edit, local[edit])
+            s.frame(cams[:2], _lib.YH_FRAME_CULL_ONLY)
+            check(2, cams[:2], "pending edits do not show yet")
+            assert s.changed_counts() == (0, 0)
+            assert np.array_equal(s.world_soa().view(np.uint32), before.view(np.uint32))
+            oracle.frame_aos68(world, local, par, lo, root)
             s.frame(cams[:2], 0)
+            assert_same_values(s.world_aos68()["m"], world["m"], "the full frame after")
+            check(2, cams[:2], "the full frame after")
+            assert s.changed_counts()[0] == n
         with pytest.raises(_lib.YumeHipError) as e:
             s.frame(cams[:2], _lib.YH_FRAME_CULL_ONLY | _lib.YH_FRAME_ALL_DIRTY)
         assert e.value.code == _lib.YH_ERR_BAD_ARG

@@ -40,15 +40,19 @@ def timed(flags, frames=200):
     return (time.perf_counter() - t0) / frames * 1e6
 
 
-mode = sys.argv[3] if len(sys.argv) > 3 else "all"  # "dirty" / "clean": one kind of frame only, change tracking on (profiling runs)
+mode = sys.argv[3] if len(sys.argv) > 3 else "all"  # "dirty" / "clean" / "cull": one kind of frame only, change tracking on (profiling runs)
 if mode != "all":
     s.track_changes(True)
-    us = timed(_lib.YH_FRAME_ALL_DIRTY if mode == "dirty" else 0, 100)
-    print(f"n={n} L={levels} change tracking on, {'every row' if mode == 'dirty' else 'nothing'} dirty: {us:8.1f} us/frame, kernels {s.group_kernel_names()}")
+    if mode == "cull":
+        s.frame(planes, 0)
+    us = timed({"dirty": _lib.YH_FRAME_ALL_DIRTY, "cull": _lib.YH_FRAME_CULL_ONLY}.get(mode, 0), 100)
+    what = {"dirty": "every row dirty", "cull": "cull only"}.get(mode, "nothing dirty")
+    print(f"n={n} L={levels} change tracking on, {what}: {us:8.1f} us/frame, kernels {s.group_kernel_names()}")
     sys.exit(0)
 for track in (False, True):
     s.track_changes(track)
     a = timed(_lib.YH_FRAME_ALL_DIRTY)
     b = timed(0)
     print(f"n={n} L={levels} change tracking {'on ' if track else 'off'}: all dirty {a:8.1f} us/frame ({n / a / 1e3:.1f} Gent/s), "
-          f"nothing dirty {b:8.1f} us/frame ({n / b / 1e3:.1f} Gent/s)")
+          f"nothing dirty {b:8.1f} us/frame ({n / b / 1e3:.1f} Gent/s), "
+          f"cull only {(c := timed(_lib.YH_FRAME_CULL_ONLY)):8.1f} us/frame ({n / c / 1e3:.1f} Gent/s; 88.1 B/entity read: {n * 88.14 / c / 1e6:.2f} TB/s)")

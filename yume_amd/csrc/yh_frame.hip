@@ -255,7 +255,6 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
         if (flags & (YH_FRAME_ALL_DIRTY | YH_FRAME_LISTS_ON_DEMAND))
             return fail(ctx, YH_ERR_BAD_ARG, "%s: YH_FRAME_CULL_ONLY goes with neither YH_FRAME_ALL_DIRTY nor YH_FRAME_LISTS_ON_DEMAND", who);
         if (s->frames == 0) return fail(ctx, YH_ERR_STATE, "%s: YH_FRAME_CULL_ONLY needs the world matrices of an earlier frame", who);
-        if (s->root_dirty) return fail(ctx, YH_ERR_STATE, "%s: YH_FRAME_CULL_ONLY with a dirty root row: every row below it has to be recomputed", who);
     }
     if (s->desc.local_kind == YH_LOCAL_TRS && !(flags & YH_FRAME_ALL_DIRTY) && !cull_only)
         return fail(ctx, YH_ERR_UNSUPPORTED, "%s: TRS scenes recompute every entity; pass YH_FRAME_ALL_DIRTY", who);
@@ -517,7 +516,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
             ++launches;
         }
     }
-    s->root_dirty = 0;  // the world sweep clears the root's flag too
+    if (!cull_only) s->root_dirty = 0;  // the world sweep clears the root's flag too
     if (cull) {
         // stage 3, part 2: tile prefix sums + expansion of the visibility words into ordered draw lists
         ExpandArgs x;
