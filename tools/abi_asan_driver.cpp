@@ -94,6 +94,15 @@ int main() {
         EXPECT(wr == counts[0]);
         for (size_t i = 1; i < list.size(); ++i) EXPECT(list[i] > list[i - 1]);
         EXPECT(yh_get_draw_list(s, 0, list.data(), 3, &wr) == YH_ERR_CAPACITY && wr == counts[0]);
+        // cull what the device holds: the same lists from one launch, deferred expansion of the frame before flushed
+        CK(yh_frame(s, planes, 2, YH_FRAME_ALL_DIRTY | YH_FRAME_ASYNC));
+        CK(yh_frame(s, planes, 1, YH_FRAME_CULL_ONLY | YH_FRAME_ASYNC));
+        CK(yh_frame(s, planes, 3, YH_FRAME_CULL_ONLY));
+        uint32_t counts2[8];
+        CK(yh_get_counts(s, counts2, nullptr));
+        EXPECT(counts2[0] == counts[0]);
+        EXPECT(yh_frame(s, planes, 1, YH_FRAME_CULL_ONLY | YH_FRAME_ALL_DIRTY) == YH_ERR_BAD_ARG);
+        EXPECT(yh_frame_static(s, planes, 1, YH_FRAME_CULL_ONLY) == YH_ERR_UNSUPPORTED);
         // world rows out, both formats
         std::vector<float> soa(16 * (size_t)n);
         float* pl[16];
