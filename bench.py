@@ -641,6 +641,24 @@ def run_mat4(job):
         "visible_fraction": [round(float(counts[0]) / n, 4)],
         "changed_rows": {"world": int(nw), "local": int(nl)},
     }
+    # the other two kinds of frame the drop-in sends on this scene (never `value`): nothing dirty (the rule finds every
+    # row clean), and YH_FRAME_CULL_ONLY (only a camera moved: one launch over the world rows the device holds)
+    flags = _lib.YH_FRAME_ASYNC
+    for _ in range(5):
+        s.frame(planes, flags)
+    clean_ms = timed(100) / 100 * 1e3
+    flags = _lib.YH_FRAME_ASYNC | _lib.YH_FRAME_CULL_ONLY
+    for _ in range(5):
+        s.frame(planes, flags)
+    cull_ms = timed(100) / 100 * 1e3
+    cull_bytes = n * (64 + 24 + 1 / 8 + 1 / 64) + 4.0 * float(counts[0])  # world row, AABB in; visibility bit + count byte, list out
+    rec["other_frames"] = {
+        "nothing_dirty_ms": round(clean_ms, 5),
+        "cull_only_ms": round(cull_ms, 5),
+        "cull_only_Mentities_per_s": round(n / cull_ms / 1e3, 2),
+        "cull_only_frame_hbm_frac": round(cull_bytes / (cull_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "cull_only_kernel": s.group_kernel_names()[0],
+    }
     s.close()
     return rec
 
@@ -758,7 +776,8 @@ def main():
         if not job.all_ok(ok):  # a rank failed: the others would wait for it in the next workload's collectives
             break
     # the drop-in's own path (Mat4 columns, literal rule, change tracking): one GPU only - it is what ONE engine process runs
-    if subs and world_size == 1 and not args.sub and "_error" not in result["workloads"]:
+    want_mat4 = (subs and not args.sub) or (not args.no_sub and "mat4" in args.sub.split(","))
+    if want_mat4 and world_size == 1 and "_error" not in result["workloads"]:
         try:
             result["workloads"]["mat4"] = run_mat4(job)
         except Exception as ex:  # noqa: BLE001
