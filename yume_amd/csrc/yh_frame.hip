@@ -395,14 +395,15 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
             a.begin = 0;
             a.end = (uint32_t)s->n;
             const dim3 grid((uint32_t)cdiv(s->n, YH_BLOCK));
-            if (bounds == 1) hipLaunchKernelGGL((k_cull_only<1>), grid, dim3(YH_BLOCK), 0, st, a);
-            else hipLaunchKernelGGL((k_cull_only<2>), grid, dim3(YH_BLOCK), 0, st, a);
+            uint32_t* const chg = s->track ? s->h_chg_dev : nullptr;  // no row changed: both change lists are empty
+            if (bounds == 1) hipLaunchKernelGGL((k_cull_only<1>), grid, dim3(YH_BLOCK), 0, st, a, chg);
+            else hipLaunchKernelGGL((k_cull_only<2>), grid, dim3(YH_BLOCK), 0, st, a, chg);
             HIP_TRY(ctx, hipGetLastError());
             if (!s->group_kernel.empty()) s->group_kernel[0] = bounds == 1 ? "k_cull_only<1>" : "k_cull_only<2>";
             ++launches;
         }
-        if (s->track) {  // no row changed: both change lists are empty
-            HIP_TRY(ctx, hipMemsetAsync(s->h_chg_dev, 0, 2 * sizeof(uint32_t), st));
+        if (s->track) {
+            if (!cull) HIP_TRY(ctx, hipMemsetAsync(s->h_chg_dev, 0, 2 * sizeof(uint32_t), st));
             s->chg_valid = true;
         }
     } else if (s->desc.local_kind == YH_LOCAL_TRS) {

@@ -603,8 +603,9 @@ __global__ __launch_bounds__(YH_BLOCK) __attribute__((amdgpu_waves_per_eu(6))) v
 // YH_FRAME_CULL_ONLY: the world matrices of the last frame against this frame's frusta, every slot of the scene in one
 // launch (no hierarchy: a row is a row).
 template <int BOUNDS>
-__global__ __launch_bounds__(YH_BLOCK) void k_cull_only(const FrameArgs a) {
+__global__ __launch_bounds__(YH_BLOCK) void k_cull_only(const FrameArgs a, uint32_t* __restrict__ changed_counts) {
     const uint32_t tid = threadIdx.x;
+    if (changed_counts && blockIdx.x == 0 && tid < 2) changed_counts[tid] = 0;  // change tracking: this frame changed no row
     const uint64_t e64 = (uint64_t)blockIdx.x * YH_BLOCK + tid;
     if (e64 - (tid & 63u) >= a.end) return;  // wave-uniform
     const bool valid = e64 < a.end;
