@@ -234,6 +234,12 @@ int yh_upload_world_rows_aos68(yh_scene* s, const uint32_t* slots, const void* r
  * copies are older than the scene's (frames ran with the results left on the device, §8f N2) and whose tables are now
  * re-ordered - the GPU twin of flecs moving a row between tables on re-parenting (ecs.zig:470-477).               */
 int yh_move_rows(yh_scene* s, const uint32_t* src_slots, const uint32_t* dst_slots, uint64_t count);
+/* enable: 0 off; YH_TRACK_ROWS: the two lists as described below; YH_TRACK_REWRITTEN_LOCALS: the LocalTransform list
+ * (which = 1) holds only the rows whose MATRIX the frame rewrote (reverse branch) - for a host that clears the dirty byte
+ * of every LocalTransform row at the moment it sends it (the frame would leave exactly that row: same matrix, flag
+ * cleared), so that frames in which gameplay sets local transforms bring no LocalTransform row back at all. */
+#define YH_TRACK_ROWS 1
+#define YH_TRACK_REWRITTEN_LOCALS 2
 int yh_scene_track_changes(yh_scene* s, int enable);
 int yh_get_changed_count(yh_scene* s, uint64_t* n_changed);
 int yh_download_changed_aos68(yh_scene* s, uint32_t* slots, void* world_rows, void* local_rows, uint64_t cap,

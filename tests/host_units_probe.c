@@ -18,7 +18,13 @@ static void report(const char* name, int ok) {
     if (!ok) failed = 1;
 }
 
+static void* pool_probe_job(void* arg) {
+    atomic_fetch_add((_Atomic uint32_t*)arg, 1);
+    return NULL;
+}
+
 int main(void) {
+#ifndef PROBE_POOL_ONLY /* (the ThreadSanitizer build is after the worker pool alone) */
     /* keys as flecs makes them: a 32-bit index and a generation in the high half, some slots empty (0) */
     const uint64_t n = 300000;
     ecs_entity_t* keys = (ecs_entity_t*)malloc(sizeof(ecs_entity_t) * n);
@@ -78,5 +84,34 @@ int main(void) {
         free(ref);
     }
     free(keys);
+#endif
+    {   /* the workers that outlive a frame: every job of every batch runs exactly once, whoever takes it - workers awake,
+         * workers asleep (a pause before the batch), more jobs than workers, no jobs, begin .. the caller's own work .. finish,
+         * stop and start again with another number of threads */
+        int ok = 1;
+        static _Atomic uint32_t ran[MAX_THREADS];
+        for (int threads = 1; threads <= 16 && ok; threads = threads == 1 ? 5 : threads * 3 + 1) { /* 1, 5, 16 */
+            Pool p;
+            memset(&p, 0, sizeof p);
+            pool_start(&p, threads);
+            ok = ok && p.n_workers == (uint32_t)threads - 1;
+            for (uint32_t batch = 0; batch < 3000 && ok; ++batch) {
+                const uint32_t jobs = (uint32_t)(rnd() % (MAX_THREADS + 1));
+                void* args[MAX_THREADS];
+                for (uint32_t j = 0; j < MAX_THREADS; ++j) {
+                    atomic_store(&ran[j], 0);
+                    args[j] = (void*)&ran[j];
+                }
+                if (batch % 500 == 499) usleep(3000); /* the workers have gone to sleep */
+                pool_begin(&p, pool_probe_job, args, jobs);
+                if (batch % 3 == 0) sched_yield(); /* (the caller's own part of the work) */
+                pool_finish(&p);
+                for (uint32_t j = 0; j < MAX_THREADS && ok; ++j) ok = atomic_load(&ran[j]) == (j < jobs ? 1u : 0u);
+            }
+            pool_stop(&p);
+            pool_stop(&p); /* (a second stop finds nothing to do) */
+        }
+        report("worker_pool", ok);
+    }
     return failed;
 }

@@ -121,8 +121,9 @@ def test_structural_change_observers_of_the_gpu_system_inside_real_flecs(tmp_pat
 
 
 def test_host_data_structures_of_the_gpu_system(tmp_path):
-    """The partitioned map filled by helper threads (1, 4, 16), its reuse, small maps, and the radix sort of tables by
-    parent slot against qsort: tests/host_units_probe.c includes GpuTransformCullSystem.c and calls the static functions
+    """The partitioned map filled by helper threads (1, 4, 16), its reuse, small maps, the radix sort of tables by
+    parent slot against qsort, and the workers that outlive a frame (every job of 9000 batches exactly once; once more
+    under ThreadSanitizer): tests/host_units_probe.c includes GpuTransformCullSystem.c and calls the static functions
     as they are (CPU only)."""
     import subprocess
 
@@ -139,7 +140,18 @@ def test_host_data_structures_of_the_gpu_system(tmp_path):
                            "-lyume_hip", f"-Wl,-rpath,{os.path.join(root, 'yume_amd')}", "-lm", "-lpthread"])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     rows = [line.split() for line in r.stdout.splitlines()]
-    assert len(rows) == 6, r.stdout + r.stderr
+    assert len(rows) == 7, r.stdout + r.stderr
     for name, verdict in rows:
         assert verdict == "ok", f"{name}: {verdict}"
     assert r.returncode == 0
+    # the worker pool once more under ThreadSanitizer (host code only: nothing here touches a device)
+    tsan = tmp_path / "units_tsan"
+    built = subprocess.run(["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=thread", "-Wno-unused-function", "-DFLECS_CONFIG_HEADER=1",
+                            "-DPROBE_POOL_ONLY=1", "-I", flecs_h, "-I", os.path.join(root, "yume_amd", "host"),
+                            "-I", os.path.join(root, "include"), "-o", str(tsan), os.path.join(root, "tests", "host_units_probe.c"),
+                            flecs_o, "-L", os.path.join(root, "yume_amd"), "-lyume_hip",
+                            f"-Wl,-rpath,{os.path.join(root, 'yume_amd')}", "-lm", "-lpthread"], capture_output=True, text=True)
+    if built.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime for gcc here: " + built.stderr[-300:])
+    r = subprocess.run([str(tsan)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "worker_pool ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr[-3000:]

@@ -201,9 +201,12 @@ def test_random_edit_scripts_on_flecs_columns(ctx, oracle, seed):
                     assert_same_values(lr["m"], local["m"][slots], "changed local rows")
 
 
-def test_sparse_rows_and_change_tracking(ctx, oracle):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_sparse_rows_and_change_tracking(ctx, oracle, mode):
     """only dirty rows go up, only rows the frame touched come back.  A host mirror patched with the
-    returned rows must equal the oracle's full columns after every frame, and untouched frames return nothing."""
+    returned rows must equal the oracle's full columns after every frame, and untouched frames return nothing.
+    mode 2 (YH_TRACK_REWRITTEN_LOCALS): the LocalTransform list holds the reverse-branch rows alone - the host clears
+    the flags of the local rows it sent itself - and the mirror still equals the oracle's columns."""
     from yume_amd import Scene, _lib
 
     n = 80_000
@@ -219,7 +222,10 @@ def test_sparse_rows_and_change_tracking(ctx, oracle):
         s.upload_aabb(np.ascontiguousarray(bounds[:, 0:3].T), np.ascontiguousarray(bounds[:, 3:6].T))
         s.upload_local_aos68(local)
         s.upload_world_aos68(world)
-        s.track_changes(True)
+        with pytest.raises(_lib.YumeHipError) as e:
+            s.track_changes(3)
+        assert e.value.code == _lib.YH_ERR_BAD_ARG
+        s.track_changes(mode)
         mirror_w, mirror_l = world.copy(), local.copy()  # what the host (flecs) holds
 
         def step(tag, expect_changed=None):
@@ -253,7 +259,7 @@ def test_sparse_rows_and_change_tracking(ctx, oracle):
                 wd_after[a:b] = pd | ld | wd
                 reverse[a:b] = wd & ~ld & ~pd
             assert np.array_equal(sw, np.flatnonzero(wd_after)), tag
-            assert np.array_equal(sl, np.flatnonzero(reverse | (before_l["dirty"] != 0))), f"{tag}: LocalTransform list"
+            assert np.array_equal(sl, np.flatnonzero(reverse | ((before_l["dirty"] != 0) & (mode == 1)))), f"{tag}: LocalTransform list"
             assert np.array_equal(rl2, rl[np.searchsorted(slots, sl)]), tag
             assert np.isin(np.flatnonzero(np.any(local["m"].view(np.uint32) != before_l["m"].view(np.uint32), axis=1)), sl).all(), tag
             mirror_w[slots] = rw
@@ -276,6 +282,8 @@ def test_sparse_rows_and_change_tracking(ctx, oracle):
             local["m"][e_] = oracle.compose(rng.uniform(-5, 5, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
         local["dirty"][idx] = 1
         s.upload_local_rows(idx, local[idx])
+        if mode == 2:
+            mirror_l[idx] = local[idx]  # the host's own edit: such a row does not come back in this mode
         step("frame 2 (sparse local edits)")
 
         idx = np.unique(rng.integers(int(lo[1]), n, 250)).astype(np.uint32)
@@ -290,6 +298,8 @@ def test_sparse_rows_and_change_tracking(ctx, oracle):
         local["m"][leaf] = oracle.compose([1, 1, 1], [0, 0, 0, 1], [1, 1, 1])
         local["dirty"][leaf] = 1
         s.upload_local_rows(leaf, local[leaf])
+        if mode == 2:
+            mirror_l[leaf] = local[leaf]
         step("frame 5 (one leaf)", expect_changed=1)
 
         with pytest.raises(_lib.YumeHipError) as e:

@@ -34,6 +34,8 @@ YH_FRAME_ASYNC = 0x4
 YH_FRAME_ORDERED = 0x8
 YH_FRAME_LISTS_ON_DEMAND = 0x10
 YH_FRAME_CULL_ONLY = 0x20
+YH_TRACK_ROWS = 1
+YH_TRACK_REWRITTEN_LOCALS = 2
 
 
 class SceneDesc(C.Structure):

@@ -320,7 +320,7 @@ class Scene:
         self._ck(L.lib().yh_move_rows(self._h, _ptr(src), _ptr(dst), src.size))
 
     def track_changes(self, enable=True):
-        self._ck(L.lib().yh_scene_track_changes(self._h, int(bool(enable))))
+        self._ck(L.lib().yh_scene_track_changes(self._h, int(enable)))  # True / YH_TRACK_ROWS, YH_TRACK_REWRITTEN_LOCALS
 
     def changed(self):
         """(slots, world rows, local rows) the last frame recomputed or found edited; ascending slots."""

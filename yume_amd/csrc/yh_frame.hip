@@ -485,7 +485,7 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
         // PostWorldTransform / PostLocalTransform (PostTransformSystem.zig:12-37)
         if (s->track) {
             hipLaunchKernelGGL(k_sweep_dirty, dim3(cdiv(s->stride, YH_BLOCK * 16ull)), dim3(YH_BLOCK), 0, st, s->ldirty, s->wdirty,
-                               (uint32_t)s->n, s->chg_words, s->chg_cnt, s->n_chunks, s->cnt_stride, s->alive);
+                               (uint32_t)s->n, s->chg_words, s->chg_cnt, s->n_chunks, s->cnt_stride, s->alive, s->track_rewritten_only ? 1u : 0u);
             HIP_TRY(ctx, hipGetLastError());
             ExpandArgs c;
             memset(&c, 0, sizeof c);

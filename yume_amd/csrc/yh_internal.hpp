@@ -107,6 +107,7 @@ struct yh_scene {
     uint32_t pend_frusta = 0;
     // change tracking (Mat4 scenes, yh_scene_track_changes): mask of rows a frame touched -> ascending slot list
     bool track = false;
+    bool track_rewritten_only = false;  // YH_TRACK_REWRITTEN_LOCALS: the LocalTransform list holds the reverse-branch rows only
     uint32_t* chg = nullptr;          // device: 32 count words | tile counts | mask words (one allocation)
     uint32_t* chg_tilecnt = nullptr;
     uint64_t* chg_words = nullptr;

@@ -835,7 +835,8 @@ __global__ __launch_bounds__(YH_BLOCK) void k_expand(const ExpandArgs x) { expan
 //   mask 0: LocalTransform.dirty or WorldTransform.dirty - every row this frame recomputed or found edited (its
 //           WorldTransform row, matrix or flag, differs from what the host holds);
 //   mask 1: LocalTransform.dirty, or the frame re-derived the local matrix (reverse branch) - the rows whose
-//           LocalTransform differs from what the host holds.  A root that moves dirties every world matrix below it and
+//           LocalTransform differs from what the host holds (rewritten_only: the reverse-branch rows alone - a host
+//           that cleared the flag of every LocalTransform row it sent holds the others as the frame leaves them).  A root that moves dirties every world matrix below it and
 //           not one local matrix: only mask 0's rows need to cross PCIe.
 // k_count / k_expand turn the masks into ascending lists of slots, exactly as they do for two frusta.
 // Sixteen entities per lane (one 16-byte load per flag plane: a byte per lane and instruction costs the memory pipeline
@@ -848,8 +849,9 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {  // bit i = byte
 __global__ __launch_bounds__(YH_BLOCK) void k_sweep_dirty(uint8_t* __restrict__ ld, uint8_t* __restrict__ wd, uint32_t n,
                                                           uint64_t* __restrict__ words, uint8_t* __restrict__ counts,
                                                           uint32_t n_chunks, uint32_t cnt_stride,
-                                                          const uint64_t* __restrict__ alive) {
+                                                          const uint64_t* __restrict__ alive, const uint32_t rewritten_only) {
     const uint64_t e0 = ((uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x) * 16u;  // this lane's first entity
+    const uint32_t keep_set = rewritten_only ? 0u : 0xFu;  // YH_TRACK_REWRITTEN_LOCALS: mask 1 = reverse-branch rows only
     const uint64_t padded = ((uint64_t)n + 63u) & ~63ull;                         // the planes' length: whole chunks
     uint32_t m = 0, ml = 0;
     if (e0 < padded) {
@@ -860,7 +862,7 @@ __global__ __launch_bounds__(YH_BLOCK) void k_sweep_dirty(uint8_t* __restrict__ 
             const uint32_t lnz = nonzero_bytes(lq[q]);
             m |= (lnz | nonzero_bytes(wq[q])) << (4 * q);
             // bytes equal to YH_WDIRTY_LOCAL_REWRITTEN: the zero bytes of the xor
-            ml |= (lnz | (~nonzero_bytes(wq[q] ^ (0x01010101u * YH_WDIRTY_LOCAL_REWRITTEN)) & 0xFu)) << (4 * q);
+            ml |= ((lnz & keep_set) | (~nonzero_bytes(wq[q] ^ (0x01010101u * YH_WDIRTY_LOCAL_REWRITTEN)) & 0xFu)) << (4 * q);
         }
         const uint32_t valid = e0 + 16u <= n ? 0xFFFFu : (e0 < n ? (1u << (uint32_t)(n - e0)) - 1u : 0u);  // rows past n are padding
         m &= valid;

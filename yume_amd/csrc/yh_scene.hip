@@ -907,7 +907,9 @@ extern "C" int yh_scene_track_changes(yh_scene* s, int enable) {
         HIP_TRY(ctx, hipHostGetDevicePointer((void**)&s->h_chg_dev, s->h_chg, 0));
         memset(s->h_chg, 0, 2 * YH_MAX_FRUSTA * 4);
     }
+    if (enable < 0 || enable > YH_TRACK_REWRITTEN_LOCALS) return fail(ctx, YH_ERR_BAD_ARG, "yh_scene_track_changes: enable must be 0, 1 or 2");
     s->track = enable != 0;
+    s->track_rewritten_only = enable == YH_TRACK_REWRITTEN_LOCALS;
     s->chg_valid = false;
     return YH_OK;
 }

@@ -40,7 +40,8 @@
 #define MESH_TABLE_MAX 65536u /* distinct meshes (+ entities with bounds of their own) a mesh-table scene can hold */
 #define SPARE_MIN 1024u /* spare slots every level gets at least (a pasted subtree, a burst of spawns) */
 #define SPARE_LEVELS 2u /* empty levels below the deepest one: a subtree dragged under a leaf is patched, not rebuilt */
-#define ROWS_PER_THREAD_MIN 2048u /* below this many changed rows per helper a thread costs more than it saves */
+#define ROWS_PER_THREAD_MIN 2048u /* below this many changed rows per helper a thread made for the call costs more than it saves */
+#define ROWS_PER_WORKER_MIN 512u  /* the same for the workers that outlive the frame (GpuTransformCullSystem_pool.inc) */
 
 typedef struct Batch {
     void* world_col;
@@ -78,6 +79,8 @@ typedef struct BoundsEntry {
     ecs_entity_t key;
     float mm[6];
 } BoundsEntry;
+
+#include "GpuTransformCullSystem_pool.inc"
 
 struct GpuTransformCullSystem {
     ecs_world_t* world;
@@ -159,6 +162,9 @@ struct GpuTransformCullSystem {
     int readback;            /* 1 (default): rows a frame changed come back into the flecs columns; 0: they stay on the device */
     int host_stale;          /* frames ran without readback: the next frame with readback brings whole columns back */
     int threads;             /* helpers for copying changed rows back into the tables (1 = the calling thread only) */
+    Pool pool;               /* threads - 1 workers for the per-frame jobs, started at the first such job */
+    int frame_rebuilt;       /* this frame sent whole columns (stage_l / stage_w hold them by slot) */
+    int host_clears_local;   /* the scene tracks YH_TRACK_REWRITTEN_LOCALS: every LocalTransform row sent has its dirty byte cleared here */
     Map slot_of;             /* entity -> slot, valid between rebuilds */
     ecs_entity_t* dirty[2];  /* [0] LocalTransform, [1] WorldTransform: entities set since the last frame */
     uint64_t n_dirty[2], cap_dirty[2];
@@ -253,7 +259,12 @@ static int camera_world_this_frame(GpuTransformCullSystem* s, ecs_entity_t e, fl
             memcpy(wrow, w, ROW);
             memcpy(lrow, l, ROW);
         }
-        const int ld = lrow[64] != 0, wd = wrow[64] != 0;
+        int ld = lrow[64] != 0;
+        const int wd = wrow[64] != 0;
+        /* a LocalTransform row that went up this frame had its flag cleared in the table at that moment (gather_range,
+         * columns_thread): the flag the frame will read is the one that was sent */
+        if (!s->host_stale && s->host_clears_local)
+            ld = ld || (s->frame_rebuilt ? s->stage_l[(size_t)chain_slot[i] * ROW + 64] != 0 : s->stamp[0][chain_slot[i]] == s->epoch);
         if (!pdirty && !ld && !wd) { /* :62-64: the row stays as it is */
             memcpy(pm, wrow, 64);
         } else if (ld || pdirty) { /* :67-68 */
@@ -393,6 +404,7 @@ static void run(ecs_iter_t* it) {
         return;
     }
     const double t_inputs = now_ms();
+    s->frame_rebuilt = rebuilt;
     if (!s->incremental || rebuilt) {
         /* whole columns up; in plain mode whole columns down again */
         copy_columns(s, 1);
@@ -513,14 +525,31 @@ static void run(ecs_iter_t* it) {
          * components come back separately: a parent that moved rewrote every WorldTransform below it and no
          * LocalTransform, so only the world rows cross PCIe. */
         uint64_t mw = 0, ml = 0;
-        if ((rc = yh_get_changed_counts(s->scene, &mw, &ml)) != YH_OK || (mw && (rc = fetch_changed(s, 1, mw)) != YH_OK) ||
-            (ml && (rc = fetch_changed(s, 0, ml)) != YH_OK)) {
+        static int trace = -1; /* YUME_GPU_SYSTEM_TRACE=1: the steps with their wall time on stderr */
+        if (trace < 0) trace = getenv("YUME_GPU_SYSTEM_TRACE") != NULL;
+        const double t0 = trace ? now_ms() : 0;
+        rc = yh_get_changed_counts(s->scene, &mw, &ml);
+        const double t1 = trace ? now_ms() : 0;
+        if (rc == YH_OK && mw) rc = fetch_changed(s, 1, mw);
+        const double t2 = trace ? now_ms() : 0;
+        if (rc == YH_OK && ml) rc = fetch_changed(s, 0, ml);
+        if (trace)
+            fprintf(stderr, "  rows down: counts %.3f ms, %llu WorldTransform rows %.3f ms, %llu LocalTransform rows %.3f ms\n", t1 - t0,
+                    (unsigned long long)mw, t2 - t1, (unsigned long long)ml, now_ms() - t2);
+        if (rc != YH_OK) {
             s->status = rc;
             return;
         }
         s->last_down_rows = mw + ml;
     }
     s->n_dirty[0] = s->n_dirty[1] = 0;
+    if (rebuilt && s->incremental && s->n_slots) {
+        /* The first small device-to-host copy after a scene's set-up can take the HIP runtime 5-6 ms (seen after the
+         * pageable uploads of a mesh table: 27 KB of slots took 5.6 ms to enqueue, once).  One row, here, at the end of a
+         * frame that cost a rebuild anyway, so that the first frame with a few edited rows does not pay it. */
+        uint8_t row[ROW];
+        (void)yh_download_world_aos68(s->scene, s->pinned ? s->stage_w : row, 0, 1);
+    }
     if (root_row) root_row[64] = 0; /* PostWorldTransform reaches the root too (single-term query) */
     s->frame_n_frusta = s->n_frusta; /* what this frame was computed from: the next one may find it has nothing to do */
     memcpy(s->frame_planes, s->planes, sizeof s->frame_planes);
@@ -900,6 +929,7 @@ int GpuTransformCullSystem_fetchWorld(GpuTransformCullSystem* s, ecs_entity_t en
 
 int GpuTransformCullSystem_setThreads(GpuTransformCullSystem* s, int n) {
     if (!s || n < 1) return YH_ERR_BAD_ARG;
+    pool_stop(&s->pool); /* started again with the new number by the next job */
     s->threads = n > MAX_THREADS ? MAX_THREADS : n;
     return YH_OK;
 }
@@ -928,6 +958,7 @@ void GpuTransformCullSystem_lastTraffic(const GpuTransformCullSystem* s, uint64_
 
 void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     if (!s) return;
+    pool_stop(&s->pool);
     if (s->scene) yh_scene_destroy(s->scene);
     if (s->camera_query) ecs_query_fini(s->camera_query);
     free(s->batches);

@@ -166,9 +166,11 @@ uint64_t GpuTransformCullSystem_cullOnlyFrames(const GpuTransformCullSystem* s);
  * world matrix from the device, whatever the mode (the gizmo reads the selected entity's: SceneWindow.zig:334-351). */
 int GpuTransformCullSystem_setReadback(GpuTransformCullSystem* s, int on);
 int GpuTransformCullSystem_fetchWorld(GpuTransformCullSystem* s, ecs_entity_t entity, float matrix[16]);
-/* Helpers that share the copy of changed rows back into the tables when a frame changed many (default: the CPUs
- * online, at most 8; 1 = the calling thread only).  They live for that one copy; the system owns no thread between
- * frames. */
+/* Threads that share the host side of a frame (default: the CPUs online, at most 16; 1 = the calling thread only).
+ * The per-frame jobs - edited rows gathered from their tables, changed rows placed back into them - go to n - 1 workers
+ * that are started by the first such job and live until _destroy (or the next _setThreads): asleep on a condition variable
+ * between frames, so they cost nothing while nothing moves.  The rare long jobs (a walk, a rebuild, whole columns) still
+ * make threads of their own for the one call. */
 int GpuTransformCullSystem_setThreads(GpuTransformCullSystem* s, int n);
 /* 68-byte rows that crossed PCIe in the last frame, each direction (both components counted). */
 /* Wall time of the last frame by stage, ms: [0] tables, root, bounds, frusta; [1] changed rows gathered and sent up;
