@@ -200,6 +200,8 @@ struct GpuTransformCullSystem {
     Map table_batch;              /* table pointer -> its live batch (rebuilt with the slots, kept up to date by patch()) */
     uint64_t table_batch_entries;
     int patch_index_valid;        /* table_batch / slot_has_kids describe the batches (rebuild() clears it) */
+    pthread_t index_thread;       /* builds them in the background after a rebuilt frame (index_begin / index_join) */
+    int index_thread_live;
     uint8_t* slot_has_kids;       /* per slot: some batch names it as its parent slot (set, never cleared between rebuilds) */
 
     int status;
@@ -214,6 +216,25 @@ struct GpuTransformCullSystem {
 #include "GpuTransformCullSystem_observers.inc"
 #include "GpuTransformCullSystem_rows.inc"
 #include "GpuTransformCullSystem_patch.inc"
+
+/* The look-up tables of patch() cost 7 ms at 300k tables.  The rebuild does not build them (the first frame is long
+ * enough), the first patch used to; now a thread builds them once the rebuilt frame is over, while the engine goes on:
+ * by the time something structural happens they are there (a first re-parented leaf: 7.2 -> 0.35 ms).  The thread reads
+ * the batches' tables, counts and parent slots, which nothing writes while frames are clean; whatever is about to change
+ * them joins it first. */
+static void* index_thread_main(void* arg) {
+    patch_index_build((GpuTransformCullSystem*)arg);
+    return NULL;
+}
+static void index_join(GpuTransformCullSystem* s) {
+    if (!s->index_thread_live) return;
+    pthread_join(s->index_thread, NULL);
+    s->index_thread_live = 0;
+}
+static void index_begin(GpuTransformCullSystem* s) {
+    if (s->index_thread_live || s->patch_index_valid || !s->patching || !s->incremental || getenv("YUME_GPU_SYSTEM_LAZY_INDEX")) return;
+    s->index_thread_live = pthread_create(&s->index_thread, NULL, index_thread_main, s) == 0;
+}
 
 static double now_ms(void) {
     struct timespec t;
@@ -295,6 +316,7 @@ static void run(ecs_iter_t* it) {
                 it->query && ecs_query_match_count(it->query) == s->cached_match_count;
     s->last_up_rows = 0;
     s->last_patch_tables = 0;
+    if (!clean) index_join(s); /* the batches are about to change */
     if (!clean && s->patching && s->incremental && s->skip_walks && s->trust_observers &&
         !s->need_full && s->scene && s->cached_n && s->batches_live && it->query) {
         /* rows entered or left a few tables: move just those (no walk of the query, no rebuild) */
@@ -561,6 +583,7 @@ static void run(ecs_iter_t* it) {
     s->last_ms[2] = t_frame - t_up;
     s->last_ms[3] = now_ms() - t_frame;
     s->status = YH_OK;
+    if (rebuilt) index_begin(s);
 }
 
 /* ---- public ------------------------------------------------------------------------------------------------ */
@@ -958,6 +981,7 @@ void GpuTransformCullSystem_lastTraffic(const GpuTransformCullSystem* s, uint64_
 
 void GpuTransformCullSystem_destroy(GpuTransformCullSystem* s) {
     if (!s) return;
+    index_join(s);
     pool_stop(&s->pool);
     if (s->scene) yh_scene_destroy(s->scene);
     if (s->camera_query) ecs_query_fini(s->camera_query);
