@@ -33,6 +33,7 @@ if levels > 2:
 with tempfile.TemporaryDirectory() as d:
     scene = os.path.join(d, "scene.bin")
     write_scene(scene, lo, par, local["m"], oracle.identity68()["m"][0], planes, bounds, frames)
+    only = os.environ.get("FLECS_BENCH_ONLY")  # a substring of the labels to run
     for label, binary, env in (("CPU systems (reference rule, real flecs)", CPU, {}),
                                ("GPU system, whole columns", GPU, {"YFH_PLAIN": "1"}),
                                ("GPU system, incremental, every table validated every frame (round 1)", GPU, {"YFH_VALIDATE": "1"}),
@@ -41,6 +42,8 @@ with tempfile.TemporaryDirectory() as d:
                                ("GPU system, incremental, every structural change rebuilt (setPatching(0))", GPU, {"YFH_NO_PATCH": "1"}),
                                ("GPU system, incremental, cameras and mesh bounds read from the ECS", GPU, {"YFH_ECS_INPUTS": "1"}),
                                ("GPU system, incremental, results stay on the device (last frame reads all back)", GPU, {"YFH_NO_READBACK": "1"})):
+        if only and only not in label:
+            continue
         e = dict(os.environ, YFH_TIMES="1", **env)
         for k in ("YFH_PLAIN", "YFH_VALIDATE", "YFH_ALWAYS_WALK", "YFH_NO_READBACK", "YFH_THREADS", "YFH_NO_PATCH", "YFH_ECS_INPUTS"):
             if k not in env:
@@ -49,5 +52,7 @@ with tempfile.TemporaryDirectory() as d:
         times = [line.split(": ")[1].split(" ms")[0] for line in r.stderr.splitlines() if line.startswith("frame ")]
         print(f"{label:90s} n={n} L={levels}  ms per frame: " + "  ".join(times), flush=True)
         for line in r.stderr.splitlines():
-            if line.startswith("stages ") and env in ({}, {"YFH_ECS_INPUTS": "1"}) and line.split()[1] in ("0:", "2:", "4:", "6:", "8:"):
+            if line.startswith("stages ") and (env in ({}, {"YFH_ECS_INPUTS": "1"}) or os.environ.get("FLECS_BENCH_ALL_STAGES")) and line.split()[1] in ("0:", "2:", "4:", "6:", "8:"):
                 print("    " + line, flush=True)
+            elif os.environ.get("FLECS_BENCH_ALL_STAGES") and line.startswith("  "):
+                print("    " + line[:400], flush=True)

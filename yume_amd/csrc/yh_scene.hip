@@ -66,15 +66,25 @@ extern "C" int yh_init(int device_id, yh_ctx** out) {
         return YH_ERR_HIP;  // (the message is resolve_static_scratch's)
     }
     // The process' first host <-> device copy of some size costs the runtime ~8 ms (its copy queues come up then, 1.5 ms
-    // for the same copy afterwards): paid here rather than inside somebody's first frame.  Failure is not an error.
+    // for the same copy afterwards): paid here rather than inside somebody's first frame - both directions, page-locked
+    // and ordinary memory, small and large, on the null stream and on the context's own.  Failure is not an error.
     {
         void *d = nullptr, *h = nullptr;
         const size_t bytes = 1u << 20;
-        if (hipMalloc(&d, bytes) == hipSuccess && hipHostMalloc(&h, bytes, hipHostMallocDefault) == hipSuccess) {
+        void* pageable = malloc(bytes);
+        if (hipMalloc(&d, bytes) == hipSuccess && hipHostMalloc(&h, bytes, hipHostMallocDefault) == hipSuccess && pageable) {
             memset(h, 0, bytes);
+            memset(pageable, 0, bytes);
             (void)hipMemcpy(d, h, bytes, hipMemcpyHostToDevice);
             (void)hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost);
+            for (void* host : {h, pageable})
+                for (size_t sz : {(size_t)256, (size_t)27 * 1024, bytes}) {
+                    (void)hipMemcpyAsync(d, host, sz, hipMemcpyHostToDevice, c->stream);
+                    (void)hipMemcpyAsync(host, d, sz, hipMemcpyDeviceToHost, c->stream);
+                    (void)hipStreamSynchronize(c->stream);
+                }
         }
+        free(pageable);
         if (h) (void)hipHostFree(h);
         if (d) (void)hipFree(d);
         (void)hipGetLastError();

@@ -208,6 +208,22 @@ struct GpuTransformCullSystem {
     uint64_t rebuilds;
 };
 
+/* fn(job p) for p = 0 .. parts-1, jobs of job_size bytes each in one array: part 0 on the calling thread, the others on
+ * the workers (the calling thread takes what no worker took).  Only ever called from the thread that runs the system. */
+static void run_parts(GpuTransformCullSystem* s, void* (*fn)(void*), void* jobs, size_t job_size, uint32_t parts) {
+    void* args[MAX_THREADS];
+    if (parts > MAX_THREADS) parts = MAX_THREADS;
+    for (uint32_t p = 0; p < parts; ++p) args[p] = (char*)jobs + (size_t)p * job_size;
+    if (parts < 2) {
+        if (parts) fn(args[0]);
+        return;
+    }
+    pool_start(&s->pool, s->threads);
+    pool_begin(&s->pool, fn, args + 1, parts - 1);
+    fn(args[0]);
+    pool_finish(&s->pool);
+}
+
 /* The parts, in dependency order; one translation unit (everything but the public functions at the end is static). */
 #include "GpuTransformCullSystem_map.inc"
 #include "GpuTransformCullSystem_walk.inc"
@@ -566,9 +582,11 @@ static void run(ecs_iter_t* it) {
     }
     s->n_dirty[0] = s->n_dirty[1] = 0;
     if (rebuilt && s->incremental && s->n_slots) {
-        /* The first small device-to-host copy after a scene's set-up can take the HIP runtime 5-6 ms (seen after the
-         * pageable uploads of a mesh table: 27 KB of slots took 5.6 ms to enqueue, once).  One row, here, at the end of a
-         * frame that cost a rebuild anyway, so that the first frame with a few edited rows does not pay it. */
+        /* Some time after a scene's set-up the HIP runtime spends 5-6 ms inside one hipMemcpyAsync, once (seen in the first
+         * frame with a few edited rows when cameras and meshes come from the ECS: 27 KB of slots took 5.6 ms to enqueue;
+         * warming every kind of copy up in yh_init does not prevent it, timing the calls makes it go away).  A one-row
+         * download here, at the end of a frame that cost a rebuild anyway, takes it off that frame in the default modes;
+         * with setPatching(0) it still shows in the first frame that brings every row back. */
         uint8_t row[ROW];
         (void)yh_download_world_aos68(s->scene, s->pinned ? s->stage_w : row, 0, 1);
     }

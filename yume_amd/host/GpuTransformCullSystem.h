@@ -169,8 +169,9 @@ int GpuTransformCullSystem_fetchWorld(GpuTransformCullSystem* s, ecs_entity_t en
 /* Threads that share the host side of a frame (default: the CPUs online, at most 16; 1 = the calling thread only).
  * The per-frame jobs - edited rows gathered from their tables, changed rows placed back into them - go to n - 1 workers
  * that are started by the first such job and live until _destroy (or the next _setThreads): asleep on a condition variable
- * between frames, so they cost nothing while nothing moves.  The rare long jobs (a walk, a rebuild, whole columns) still
- * make threads of their own for the one call. */
+ * between frames, so they cost nothing while nothing moves.  The long jobs of a rebuilt frame (the second half of a
+ * walk, whole columns, bounds) go to the same workers; only the fills of the hash maps make threads of their own for the
+ * one call (one of them runs on the thread that builds patch()'s look-up tables in the background). */
 int GpuTransformCullSystem_setThreads(GpuTransformCullSystem* s, int n);
 /* 68-byte rows that crossed PCIe in the last frame, each direction (both components counted). */
 /* Wall time of the last frame by stage, ms: [0] tables, root, bounds, frusta; [1] changed rows gathered and sent up;
