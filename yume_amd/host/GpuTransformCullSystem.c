@@ -41,7 +41,7 @@
 #define SPARE_MIN 1024u /* spare slots every level gets at least (a pasted subtree, a burst of spawns) */
 #define SPARE_LEVELS 2u /* empty levels below the deepest one: a subtree dragged under a leaf is patched, not rebuilt */
 #define ROWS_PER_THREAD_MIN 2048u /* below this many changed rows per helper a thread made for the call costs more than it saves */
-#define ROWS_PER_WORKER_MIN 512u  /* the same for the workers that outlive the frame (GpuTransformCullSystem_pool.inc) */
+#define ROWS_PER_WORKER_MIN 128u  /* the same for the workers that outlive the frame (GpuTransformCullSystem_pool.inc) */
 
 typedef struct Batch {
     void* world_col;
