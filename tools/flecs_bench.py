@@ -54,5 +54,5 @@ with tempfile.TemporaryDirectory() as d:
         for line in r.stderr.splitlines():
             if line.startswith("stages ") and (env in ({}, {"YFH_ECS_INPUTS": "1"}) or os.environ.get("FLECS_BENCH_ALL_STAGES")) and line.split()[1] in ("0:", "2:", "4:", "6:", "8:"):
                 print("    " + line, flush=True)
-            elif os.environ.get("FLECS_BENCH_ALL_STAGES") and line.startswith("  "):
+            elif os.environ.get("FLECS_BENCH_ALL_STAGES") and (line.startswith("  ") or "walk_tables" in line):
                 print("    " + line[:400], flush=True)
