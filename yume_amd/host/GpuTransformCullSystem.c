@@ -252,6 +252,13 @@ static void index_begin(GpuTransformCullSystem* s) {
     s->index_thread_live = pthread_create(&s->index_thread, NULL, index_thread_main, s) == 0;
 }
 
+/* YUME_GPU_SYSTEM_TRACE=1: the steps of a frame with their wall time on stderr (read once) */
+static int trace_on(void) {
+    static int on = -1;
+    if (on < 0) on = getenv("YUME_GPU_SYSTEM_TRACE") != NULL;
+    return on;
+}
+
 static double now_ms(void) {
     struct timespec t;
     clock_gettime(CLOCK_MONOTONIC, &t);
@@ -458,9 +465,14 @@ static void run(ecs_iter_t* it) {
         s->last_up_rows = patched_rows_up;
         for (int k = 0; k < 2; ++k) {
             uint8_t* stage = k == 0 ? s->stage_l : s->stage_w;
+            const double tg0 = now_ms();
             const uint64_t m = gather_dirty(s, k, stage);
+            const double tg1 = now_ms();
             rc = k == 0 ? yh_upload_local_rows_aos68(s->scene, s->slot_buf, stage, m)
                         : yh_upload_world_rows_aos68(s->scene, s->slot_buf, stage, m);
+            if (m && trace_on())
+                fprintf(stderr, "  rows up: %llu %s rows gathered %.3f ms, sent %.3f ms\n", (unsigned long long)m, k ? "WorldTransform" : "LocalTransform",
+                        tg1 - tg0, now_ms() - tg1);
             if (rc != YH_OK) {
                 s->status = rc;
                 return;
@@ -563,8 +575,7 @@ static void run(ecs_iter_t* it) {
          * components come back separately: a parent that moved rewrote every WorldTransform below it and no
          * LocalTransform, so only the world rows cross PCIe. */
         uint64_t mw = 0, ml = 0;
-        static int trace = -1; /* YUME_GPU_SYSTEM_TRACE=1: the steps with their wall time on stderr */
-        if (trace < 0) trace = getenv("YUME_GPU_SYSTEM_TRACE") != NULL;
+        const int trace = trace_on();
         const double t0 = trace ? now_ms() : 0;
         rc = yh_get_changed_counts(s->scene, &mw, &ml);
         const double t1 = trace ? now_ms() : 0;
