@@ -99,7 +99,7 @@ typedef struct yh_scene_desc {
                                      Rows uploaded or marked dirty since the last frame, a dirty root row included, stay
                                      pending for the next full frame; with change tracking on this frame reports no changed row.  Not
                                      before the first frame (YH_ERR_STATE), not with YH_FRAME_ALL_DIRTY /
-                                     _LISTS_ON_DEMAND (YH_ERR_BAD_ARG), not in yh_frame_static (YH_ERR_UNSUPPORTED) */
+                                     _LISTS_ON_DEMAND (YH_ERR_BAD_ARG); yh_frame_static takes it too              */
 
 typedef struct yh_timing {
     float last_frame_ms;    /* device time of the most recent frame (hipEvent; 0 unless kernel timing is on) */

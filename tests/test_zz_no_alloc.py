@@ -67,6 +67,13 @@ def test_frame_static_equals_frame_on_two_calls_in_a_row(ctx, oracle):
         big.frame(cams, flags)
         big.frame_static(cams)
         _same(_results(big, 3), want_big)
+        # a camera moved, nothing else did: YH_FRAME_CULL_ONLY through the static call equals yh_frame's
+        big.frame(cams[[2, 0]], _lib.YH_FRAME_CULL_ONLY)
+        want3 = _results(big, 2)
+        big.frame_static(cams[[2, 0]], _lib.YH_FRAME_CULL_ONLY)
+        _same(_results(big, 2), want3)
+        big.frame_static(cams, _lib.YH_FRAME_CULL_ONLY | _lib.YH_FRAME_ASYNC)
+        _same(_results(big, 3), want_big)
         # the words of a static frame are not the scene's: the pipelined gather must refuse them
         with pytest.raises(_lib.YumeHipError) as e:
             big.allgather_draw_lists_async()

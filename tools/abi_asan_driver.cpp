@@ -102,7 +102,9 @@ int main() {
         CK(yh_get_counts(s, counts2, nullptr));
         EXPECT(counts2[0] == counts[0]);
         EXPECT(yh_frame(s, planes, 1, YH_FRAME_CULL_ONLY | YH_FRAME_ALL_DIRTY) == YH_ERR_BAD_ARG);
-        EXPECT(yh_frame_static(s, planes, 1, YH_FRAME_CULL_ONLY) == YH_ERR_UNSUPPORTED);
+        CK(yh_frame_static(s, planes, 3, YH_FRAME_CULL_ONLY));
+        CK(yh_get_counts(s, counts2, nullptr));
+        EXPECT(counts2[0] == counts[0] && counts2[1] == counts[1]);
         // world rows out, both formats
         std::vector<float> soa(16 * (size_t)n);
         float* pl[16];

@@ -251,7 +251,6 @@ static int frame_impl(yh_scene* s, const float* planes, uint32_t n_frusta, uint3
     }
     const bool cull_only = (flags & YH_FRAME_CULL_ONLY) != 0;
     if (cull_only) {
-        if (use_static) return fail(ctx, YH_ERR_UNSUPPORTED, "%s: YH_FRAME_CULL_ONLY is a yh_frame flag", who);
         if (flags & (YH_FRAME_ALL_DIRTY | YH_FRAME_LISTS_ON_DEMAND))
             return fail(ctx, YH_ERR_BAD_ARG, "%s: YH_FRAME_CULL_ONLY goes with neither YH_FRAME_ALL_DIRTY nor YH_FRAME_LISTS_ON_DEMAND", who);
         if (s->frames == 0) return fail(ctx, YH_ERR_STATE, "%s: YH_FRAME_CULL_ONLY needs the world matrices of an earlier frame", who);
