@@ -541,6 +541,29 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
     had_children = np.zeros(n0, bool)
     had_children[par0[par0 != 0xFFFFFFFF]] = True
 
+    # the CPU systems visit tables in creation order and are parent-first only while every entity's own table
+    # is older than the tables of its children.  The model keeps the birth of every table an entity's children live in
+    # (one per parent; with ecs_inputs two: children with and without a Mesh) and never moves an entity that has, or ever
+    # had, children into a table younger than theirs - where the reference itself would read last frame's parent
+    # matrix (tools/f5_check.py shows such a case: seed 16, frame 133 of a 150-frame script before this rule).
+    def kind_of(e):
+        return int(e % 4 != 0) if ecs_inputs else 0
+
+    birth = {}
+    for e in range(n0):
+        if cur_parent[e] >= 0:
+            birth.setdefault((cur_parent[e], kind_of(e)), e)  # born with the first child of that kind (creation order)
+    seq = [n0]
+
+    def can_place(x, p):
+        tb = birth.get((p, kind_of(x)))
+        return all((x, k) not in birth or (tb is not None and tb < birth[(x, k)]) for k in (0, 1))
+
+    def placed(x, p):
+        if (p, kind_of(x)) not in birth:
+            birth[(p, kind_of(x))] = seq[0]
+        seq[0] += 1
+
     def subtree(e):
         out, stack = [], [e]
         while stack:
@@ -567,6 +590,7 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
                 e = next_new
                 next_new += 1
                 edits.append((e, 6, reparent_arg(p)))
+                placed(e, p)
                 cur_parent[e], depth[e] = p, depth[p] + 1
                 children.setdefault(p, set()).add(e)
                 alive.add(e)
@@ -581,9 +605,10 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
                 if children.get(e) or e not in alive:
                     continue
                 p = int(rng.choice(pool))
-                if p == e or depth[p] + 1 >= levels or p not in alive:
+                if p == e or depth[p] + 1 >= levels or p not in alive or not can_place(e, p):
                     continue
                 edits.append((e, 3, reparent_arg(p)))
+                placed(e, p)
                 children[cur_parent[e]].discard(e)
                 cur_parent[e], depth[e] = p, depth[p] + 1
                 children.setdefault(p, set()).add(e)
@@ -595,9 +620,10 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
                 e, p = int(rng.choice(pool)), int(rng.choice(pool))
                 if not children.get(e) or p in subtree(e) or depth[p] + 1 + height(e) >= levels:
                     continue
-                if p >= n0 or not had_children[p] or depth[p] > depth[e] - 1 or depth[e] == 0:
+                if p >= n0 or not had_children[p] or depth[p] > depth[e] - 1 or depth[e] == 0 or not can_place(e, p):
                     continue
                 edits.append((e, 3, reparent_arg(p)))
+                placed(e, p)
                 children[cur_parent[e]].discard(e)
                 shift = depth[p] + 1 - depth[e]
                 for x in subtree(e):
@@ -621,6 +647,7 @@ def test_random_structural_edits_are_patched_or_rebuilt_and_stay_equal_to_the_cp
                 e = next_new
                 next_new += 1
                 edits.append((e, 6, reparent_arg(p)))
+                placed(e, p)
                 cur_parent[e], depth[e] = p, depth[p] + 1
                 children.setdefault(p, set()).add(e)
                 alive.add(e)
