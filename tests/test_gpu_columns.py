@@ -141,7 +141,8 @@ def test_random_edit_scripts_on_flecs_columns(ctx, oracle, seed):
     world["dirty"] = 1
     root = oracle.identity68()
     planes = oracle.main_camera_planes().reshape(1, 24)
-    track = bool(seed % 2)
+    track = seed % 3  # off, both lists, YH_TRACK_REWRITTEN_LOCALS (the list of yh_download_changed_aos68 is the same in both)
+    other_cams = oracle.cascade_planes()
 
     def rnd_m(scale):
         return oracle.compose(rng.uniform(-scale, scale, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
@@ -176,7 +177,7 @@ def test_random_edit_scripts_on_flecs_columns(ctx, oracle, seed):
                         root["dirty"] = 1
                         s.set_root(root["m"][0])
             before_dirty = (local["dirty"] | world["dirty"]).astype(bool)
-            w0 = world["m"].copy()
+            w0, l0, ld0 = world["m"].copy(), local["m"].copy(), local["dirty"].astype(bool)
             oracle.frame_aos68(world, local, par, lo, root)
             s.frame(planes, flags=0)
             gw, gl = s.world_aos68(), s.local_aos68()
@@ -199,6 +200,21 @@ def test_random_edit_scripts_on_flecs_columns(ctx, oracle, seed):
                 with np.errstate(all="ignore"):
                     assert_same_values(wr["m"], world["m"][slots], "changed world rows")
                     assert_same_values(lr["m"], local["m"][slots], "changed local rows")
+                if track == 2:  # the LocalTransform list: exactly the rows whose matrix the frame rewrote
+                    sl, _rows = s.changed_rows(1)
+                    with np.errstate(all="ignore"):
+                        rewritten = ~np.all((l0 == local["m"]) | (np.isnan(l0) & np.isnan(local["m"])), axis=1)
+                    assert np.all(np.isin(np.flatnonzero(rewritten), sl)), (seed, frame)
+                    assert not np.any(ld0[sl]), f"seed {seed} frame {frame}: a row that was only set came back"
+            if rng.random() < 0.4:  # a camera moved, nothing else did: the same rows, another list, nothing reported
+                cam = other_cams[int(rng.integers(0, other_cams.shape[0]))].reshape(1, 24)
+                s.frame(cam, _lib.YH_FRAME_CULL_ONLY | (_lib.YH_FRAME_ASYNC if rng.random() < 0.5 else 0))
+                with np.errstate(all="ignore"):
+                    vis, bnd = oracle.cull(world, bounds, cam)
+                assert np.array_equal(s.draw_list(0), np.flatnonzero(vis[0]).astype(np.uint32)), (seed, frame, "cull only")
+                assert s.counts()[1][0] == np.count_nonzero(bnd[0])
+                if track:
+                    assert s.changed_counts() == (0, 0)
 
 
 @pytest.mark.parametrize("mode", [1, 2])
