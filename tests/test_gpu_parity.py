@@ -283,6 +283,18 @@ def test_random_scene_shapes_plans_and_frame_sequences(ctx, oracle, seed):
                 assert np.array_equal(s.draw_list(f), exp_set), (seed, rnd, f, s.groups().tolist())
             if rnd % 3 == 0:
                 assert_same_values(s.world_soa(), exp_w["m"].T, f"world seed {seed} round {rnd}")
+            if rng_flag.random() < 0.5:
+                # a camera moved, nothing else did (YH_FRAME_CULL_ONLY), behind whatever the frames above left pending -
+                # a deferred expansion, lists on demand nobody read: another choice of frusta over the same matrices
+                sel = rng_flag.permutation(4)[: int(rng_flag.integers(1, 5))]
+                if rng_flag.random() < 0.5:
+                    s.frame(cams[:nf], _lib.YH_FRAME_ALL_DIRTY | _lib.YH_FRAME_ASYNC | on_demand())
+                s.frame(cams[sel], _lib.YH_FRAME_CULL_ONLY | (_lib.YH_FRAME_ASYNC if rng_flag.random() < 0.5 else 0))
+                counts, bcounts = s.counts()
+                for k, f in enumerate(sel):
+                    exp_set = np.flatnonzero(vis_all[f]).astype(np.uint32) + np.uint32(base)
+                    assert counts[k] == exp_set.size and bcounts[k] == np.count_nonzero(bnd_all[f]), (seed, rnd, "cull only", k)
+                    assert np.array_equal(s.draw_list(k), exp_set), (seed, rnd, "cull only", k)
 
 
 def test_cfg3_five_frusta_1m(ctx, oracle):
