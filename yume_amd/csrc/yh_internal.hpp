@@ -144,6 +144,7 @@ struct yh_scene {
     uint64_t big_tree = YH_BIG_TREE, big_flat = YH_BIG_FLAT;  // entities from which read-once inputs are streamed (A/B: env of the same names)
     bool lds_parents = false;  // one-level launches stage their parents in LDS (yh_scene_set_lds_parents / YH_LDS_PARENTS=1)
     bool use_cull_plan = true;  // group planes by normal when some share one (YH_NO_CULL_PLAN=1 in the environment: A/B runs)
+    bool direct_rows = true;  // sparse rows to / from page-locked host memory go through the import / export kernel alone (YH_NO_DIRECT_ROWS=1: off)
     bool spec_clean = true;     // Mat4 level launches of frames expected to be mostly clean load the row's own data ahead of the flags (YH_NO_SPEC=1: A/B runs)
     uint32_t defer_first_max = 1u << 20;  // entities in a first launch that still carries the previous frame's expansion
     uint32_t max_mesh_id = 0;  // largest id ever uploaded (ids start out as 0): the table may not shrink below it

@@ -1015,6 +1015,11 @@ __global__ __launch_bounds__(YH_BLOCK) void k_aos68_to_soa(const uint32_t* __res
     }
 }
 
+__global__ __launch_bounds__(YH_BLOCK) void k_copy_u32(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * YH_BLOCK + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(YH_BLOCK) void k_soa_to_aos68(const float* __restrict__ arr,
                                                            const uint8_t* __restrict__ dirty, uint64_t first,
                                                            uint64_t count, uint32_t* __restrict__ rows,

@@ -296,6 +296,7 @@ extern "C" int yh_scene_create(yh_ctx* ctx, const yh_scene_desc* d, yh_scene** o
     if (const char* v = getenv("YH_NO_CULL_PLAN")) s->use_cull_plan = !(v[0] == '1');
     if (const char* v = getenv("YH_LDS_PARENTS")) s->lds_parents = v[0] == '1';
     if (const char* v = getenv("YH_NO_SPEC")) s->spec_clean = !(v[0] == '1');
+    if (const char* v = getenv("YH_NO_DIRECT_ROWS")) s->direct_rows = !(v[0] == '1');
     if (const char* v = getenv("YH_BIG_TREE")) s->big_tree = strtoull(v, nullptr, 10);
     if (const char* v = getenv("YH_BIG_FLAT")) s->big_flat = strtoull(v, nullptr, 10);
     if (const char* v = getenv("YH_DEFER_FIRST_MAX")) s->defer_first_max = (uint32_t)strtoul(v, nullptr, 10);
@@ -773,11 +774,37 @@ int ensure_staging(yh_scene* s, uint64_t bytes) {
 // rows per staging chunk of the AoS68 import/export (68 MB of staging)
 #define YH_AOS_CHUNK (1u << 20)
 
+// A few thousand rows between page-locked host memory and the scene: a copy engine's transfer into device staging and the
+// kernel behind it are two queues handing over to each other, ~0.15 ms of hand-over for 20 us of data.  The import /
+// export kernels read and write their 68-byte rows as coalesced dwords, which is as good across PCIe: when the caller's
+// buffers are page-locked and mapped (yh_host_alloc), rows up to this many go through the kernel alone.
+#define YH_DIRECT_ROWS_MAX 32768u
+static bool device_visible_host(const void* p, const void** dev) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // ordinary memory: not an error, the staged path takes it
+        return false;
+    }
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
+    *dev = a.devicePointer;
+    return true;
+}
+
 // host_slots (optional): row r belongs to entity host_slots[r] (sparse upload) instead of first + r
 static int upload_aos68(yh_scene* s, const void* column, uint64_t first, uint64_t count, float* planes, uint8_t* dirty,
                         const uint32_t* host_slots = nullptr) {
     HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
     if (int rc = sync_scene(s)) return rc;
+    if (host_slots && count && count <= YH_DIRECT_ROWS_MAX && s->direct_rows) {
+        const void *drows = nullptr, *dslots = nullptr;
+        if (device_visible_host(column, &drows) && device_visible_host(host_slots, &dslots)) {
+            hipLaunchKernelGGL(k_aos68_to_soa, dim3(cdiv(count, YH_BLOCK)), dim3(YH_BLOCK), 0, s->ctx->stream, (const uint32_t*)drows,
+                               count, planes, dirty, first, (const uint32_t*)dslots);
+            HIP_TRY(s->ctx, hipGetLastError());
+            HIP_TRY(s->ctx, hipStreamSynchronize(s->ctx->stream));
+            return YH_OK;
+        }
+    }
     const uint64_t chunk_rows = std::min<uint64_t>(count ? count : 1, YH_AOS_CHUNK);
     if (int rc = ensure_staging(s, chunk_rows * 72)) return rc;  // rows, then (sparse) their slots
     uint32_t* d_slots = host_slots ? (uint32_t*)((char*)s->staging + chunk_rows * 68) : nullptr;
@@ -989,6 +1016,18 @@ extern "C" int yh_download_changed_rows_aos68(yh_scene* s, int which, uint32_t* 
     const float* planes = which ? s->lmat : s->world;
     const uint8_t* dirty = which ? s->ldirty : s->wdirty;  // cleared by the sweep: rows come back with dirty = 0
     hipStream_t st = ctx->stream;
+    if (n <= YH_DIRECT_ROWS_MAX && s->direct_rows) {  // a few rows into page-locked memory: the export kernel writes them there itself
+        const void *drows = nullptr, *dslots = nullptr;
+        if (device_visible_host(rows, &drows) && (!slots || device_visible_host(slots, &dslots))) {
+            if (slots) hipLaunchKernelGGL(k_copy_u32, dim3(cdiv(n, YH_BLOCK)), dim3(YH_BLOCK), 0, st, list, (uint32_t*)dslots, n);
+            hipLaunchKernelGGL(k_soa_to_aos68, dim3(cdiv(n, YH_BLOCK)), dim3(YH_BLOCK), 0, st, planes, dirty, (uint64_t)0, n,
+                               (uint32_t*)drows, list);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (ready) ready(user, n);
+            return YH_OK;
+        }
+    }
     if (slots) HIP_TRY(ctx, hipMemcpyAsync(slots, list, n * 4, hipMemcpyDeviceToHost, st));
     // device staging for at most YH_DL_ROWS_MAX rows at a time (a 256M-row column does not get a 17 GB twin)
     if (int rc = ensure_staging(s, std::min<uint64_t>(n, YH_DL_ROWS_MAX) * 68)) return rc;
