@@ -252,6 +252,29 @@ int main() {
         CK(yh_frame(s, nullptr, 0, 0));
         CK(yh_get_changed_count(s, &changed));
         EXPECT(changed == n);
+        {   // the same through page-locked buffers: a few rows go through the import / export kernels alone, and the two
+            // ways must agree (rows and slots)
+            uint32_t* pslots = (uint32_t*)yh_host_alloc(ctx, 3 * 4);
+            unsigned char* prows = (unsigned char*)yh_host_alloc(ctx, (uint64_t)n * 68);
+            uint32_t* pcs = (uint32_t*)yh_host_alloc(ctx, (uint64_t)n * 4);
+            EXPECT(pslots && prows && pcs);
+            memcpy(pslots, slots, sizeof slots);
+            memcpy(prows, col.data(), 3 * 68);
+            for (int r = 0; r < 3; ++r) prows[r * 68 + 64] = 1;  // (as the onSet hook leaves a row that was set)
+            CK(yh_upload_local_rows_aos68(s, pslots, prows, 3));
+            CK(yh_frame(s, nullptr, 0, 0));
+            uint64_t nw = 0, nl = 0, got = 0;
+            CK(yh_get_changed_counts(s, &nw, &nl));
+            EXPECT(nw >= 3 && nw < n && nw <= 32768);
+            CK(yh_download_changed_rows_aos68(s, 0, pcs, prows, n, &got, nullptr, nullptr));
+            std::vector<uint32_t> cs2(nw);
+            std::vector<unsigned char> rows2(nw * 68);
+            CK(yh_download_changed_rows_aos68(s, 0, cs2.data(), rows2.data(), nw, &got, nullptr, nullptr));
+            EXPECT(got == nw && memcmp(cs2.data(), pcs, nw * 4) == 0 && memcmp(rows2.data(), prows, nw * 68) == 0);
+            yh_host_free(ctx, pcs);
+            yh_host_free(ctx, prows);
+            yh_host_free(ctx, pslots);
+        }
         {   // rows that change slots on the device: a rotation of three slots, and refused arguments
             const uint32_t src[3] = {5, 6, 7}, dst[3] = {6, 7, 5}, bad[1] = {n};
             std::vector<unsigned char> before(n * 68), after(n * 68);
