@@ -828,3 +828,64 @@ def test_cull_only_frames_equal_a_full_frame_with_the_same_frusta(ctx, oracle, k
         with pytest.raises(_lib.YumeHipError) as e:
             s.frame(cams[:2], _lib.YH_FRAME_CULL_ONLY | _lib.YH_FRAME_ALL_DIRTY)
         assert e.value.code == _lib.YH_ERR_BAD_ARG
+
+
+def test_sparse_rows_through_page_locked_buffers_equal_the_staged_path(ctx, oracle):
+    """A few thousand sparse rows between page-locked host memory (yh_host_alloc) and the scene go through the import /
+    export kernels alone, no copy engine, no device staging: what lands on the device and what comes back must be what
+    the staged path (ordinary numpy memory) moves - rows, slots, dirty bytes - and the frame after equals the oracle's."""
+    from yume_amd import Scene, _lib
+
+    n = 120_000
+    lo, par, bounds, local, world = build(oracle, n, 6, seed=oracle.SEED + 9)
+    root = oracle.identity68()
+    planes = oracle.main_camera_planes().reshape(1, 24)
+    rng = np.random.default_rng(77)
+    with Scene(ctx, n, n_levels=6, n_frusta=1, local_kind=_lib.YH_LOCAL_MAT4) as a, \
+         Scene(ctx, n, n_levels=6, n_frusta=1, local_kind=_lib.YH_LOCAL_MAT4) as b:
+        for s in (a, b):
+            s.upload_hierarchy(par, lo)
+            s.upload_aabb(np.ascontiguousarray(bounds[:, 0:3].T), np.ascontiguousarray(bounds[:, 3:6].T))
+            s.upload_local_aos68(local)
+            s.upload_world_aos68(world)
+            s.track_changes(_lib.YH_TRACK_REWRITTEN_LOCALS)
+            s.frame(planes, 0)
+        oracle.frame_aos68(world, local, par, lo, root)
+        for k in (1, 300, 5000, 32768, 40000):  # the last one is over the limit: staged in both scenes
+            idx = np.unique(rng.integers(0, n, k)).astype(np.uint32)
+            for e_ in idx[:200]:
+                local["m"][e_] = oracle.compose(rng.uniform(-5, 5, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+            local["dirty"][idx] = 1
+            widx = np.setdiff1d(np.unique(rng.integers(0, n, max(1, k // 4))).astype(np.uint32), idx)
+            for e_ in widx[:100]:
+                world["m"][e_] = oracle.compose(rng.uniform(-50, 50, 3), rng.uniform(-1, 1, 4), rng.uniform(0.5, 2, 3))
+            world["dirty"][widx] = 1
+            p_slots, p_rows = ctx.host_array(idx.size, np.uint32), ctx.host_array(idx.size, oracle.T68)
+            p_slots[:], p_rows[:] = idx, local[idx]
+            a.upload_local_rows(p_slots, p_rows)
+            b.upload_local_rows(idx, local[idx])
+            if widx.size:
+                w_slots, w_rows = ctx.host_array(widx.size, np.uint32), ctx.host_array(widx.size, oracle.T68)
+                w_slots[:], w_rows[:] = widx, world[widx]
+                a.upload_world_rows(w_slots, w_rows)
+                b.upload_world_rows(widx, world[widx])
+                ctx.host_free(w_slots)
+                ctx.host_free(w_rows)
+            ctx.host_free(p_slots)
+            ctx.host_free(p_rows)
+            oracle.frame_aos68(world, local, par, lo, root)
+            a.frame(planes, 0)
+            b.frame(planes, 0)
+            assert_same_values(a.world_aos68()["m"], world["m"], f"{k} rows: world through page-locked buffers")
+            assert_same_values(a.local_aos68()["m"], local["m"], f"{k} rows: local through page-locked buffers")
+            for which in (0, 1):  # the changed rows down again: page-locked destination against ordinary memory
+                nw = a.changed_counts()[which]
+                assert nw == b.changed_counts()[which]
+                d_slots, d_rows = ctx.host_array(max(1, nw), np.uint32), ctx.host_array(max(1, nw), oracle.T68)
+                sa, ra = a.changed_rows(which, out=(d_slots, d_rows))
+                sb, rb = b.changed_rows(which)
+                assert sa.size == nw == sb.size
+                assert np.array_equal(sa, sb) and np.array_equal(ra.view(np.uint8), rb.view(np.uint8)), (k, which)
+                ctx.host_free(d_slots)
+                ctx.host_free(d_rows)
+

@@ -55,6 +55,26 @@ class Context:
     def wait(self):
         L.check(L.lib().yh_wait(self._h), self._h)
 
+    def host_array(self, shape, dtype):
+        """A numpy array in page-locked, device-visible host memory (yh_host_alloc): copies to and from it run
+        asynchronously, and a few thousand sparse rows go through the import / export kernels alone.  Freed with
+        `host_free(array)`; the array must not be used afterwards."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape))
+        p = L.lib().yh_host_alloc(self._h, max(1, n * dtype.itemsize))
+        if not p:
+            raise MemoryError("yh_host_alloc failed")
+        buf = (C.c_uint8 * (n * dtype.itemsize)).from_address(p)
+        a = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+        self._host = getattr(self, "_host", {})
+        self._host[a.__array_interface__["data"][0]] = p
+        return a
+
+    def host_free(self, a):
+        p = getattr(self, "_host", {}).pop(a.__array_interface__["data"][0], None)
+        if p:
+            L.lib().yh_host_free(self._h, C.c_void_p(p))
+
     def stream(self):
         return L.lib().yh_stream(self._h)
 
@@ -376,12 +396,17 @@ class Scene:
         self._ck(L.lib().yh_get_changed_counts(self._h, C.byref(nw), C.byref(nl)))
         return nw.value, nl.value
 
-    def changed_rows(self, which, on_ready=None):
+    def changed_rows(self, which, on_ready=None, out=None):
         """(slots, rows) of one component's changed rows (which: 0 WorldTransform, 1 LocalTransform), streamed:
-        on_ready(rows_ready) is called after each piece has landed."""
+        on_ready(rows_ready) is called after each piece has landed.  out = (slots, rows): the caller's own arrays
+        (e.g. Context.host_array ones) with room for the rows; views of their first n entries are returned."""
         n = self.changed_counts()[which]
-        slots = np.zeros(n, np.uint32)
-        rows = np.zeros(n, T68)
+        if out is not None:
+            assert out[0].size >= n and out[1].size >= n and out[0].dtype == np.uint32 and out[1].dtype == T68
+            slots, rows = out[0][:n], out[1][:n]
+        else:
+            slots = np.zeros(n, np.uint32)
+            rows = np.zeros(n, T68)
         wr = C.c_uint64()
         cb = L.ROWS_READY_FN((lambda user, r: on_ready(int(r))) if on_ready else 0)
         self._ck(L.lib().yh_download_changed_rows_aos68(self._h, which, _ptr(slots), _ptr(rows), n, C.byref(wr),
