@@ -427,6 +427,10 @@ int main(int argc, char** argv) {
         clock_gettime(CLOCK_MONOTONIC, &t0);
         /* PostUpdate: TransformSyncSystem, then its two dependents (ecs.zig:277-293) */
 #ifdef USE_GPU_SYSTEM
+        if (f > 0 && getenv("YFH_FRAME_GAP_MS")) { /* an engine's frames are apart: idle time between them (measurement aid) */
+            struct timespec gap = {0, 1000000L * atol(getenv("YFH_FRAME_GAP_MS"))};
+            nanosleep(&gap, NULL);
+        }
         ecs_run(w, gsys, 0.016f, NULL);
         if (GpuTransformCullSystem_status(gpu) != YH_OK) {
             fprintf(stderr, "flecs_gpu_harness: frame %u: status %d: %s\n", f, GpuTransformCullSystem_status(gpu),
