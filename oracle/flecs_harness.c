@@ -423,14 +423,14 @@ int main(int argc, char** argv) {
             if (f + 1 == n_frames) GpuTransformCullSystem_setReadback(gpu, 1);
         }
 #endif
+        if (f > 0 && getenv("YFH_FRAME_GAP_MS")) { /* an engine's frames are apart: idle time between them (measurement aid, untimed) */
+            struct timespec gap = {atol(getenv("YFH_FRAME_GAP_MS")) / 1000, 1000000L * (atol(getenv("YFH_FRAME_GAP_MS")) % 1000)};
+            nanosleep(&gap, NULL);
+        }
         struct timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
         /* PostUpdate: TransformSyncSystem, then its two dependents (ecs.zig:277-293) */
 #ifdef USE_GPU_SYSTEM
-        if (f > 0 && getenv("YFH_FRAME_GAP_MS")) { /* an engine's frames are apart: idle time between them (measurement aid) */
-            struct timespec gap = {0, 1000000L * atol(getenv("YFH_FRAME_GAP_MS"))};
-            nanosleep(&gap, NULL);
-        }
         ecs_run(w, gsys, 0.016f, NULL);
         if (GpuTransformCullSystem_status(gpu) != YH_OK) {
             fprintf(stderr, "flecs_gpu_harness: frame %u: status %d: %s\n", f, GpuTransformCullSystem_status(gpu),
