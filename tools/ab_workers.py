@@ -36,6 +36,8 @@ with tempfile.TemporaryDirectory() as d:
     for binary in (sys.argv[1:] or [GPU]):
         for rep in range(2):
             e = dict({k: v for k, v in os.environ.items() if not k.startswith("YFH_")}, YFH_TIMES="1")
+            if os.environ.get("AB_GAP_MS"):  # frames that far apart, as an engine's are (idle workers, cooler caches)
+                e["YFH_FRAME_GAP_MS"] = os.environ["AB_GAP_MS"]
             if os.environ.get("AB_ECS_INPUTS"):  # cameras and mesh bounds read from the ECS
                 e["YFH_ECS_INPUTS"] = "1"
             r = subprocess.run([binary, scene, os.path.join(d, "out.bin")], env=e, capture_output=True, text=True, timeout=1200)
